@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by RUNNING THE REFERENCE (/root/reference) in the build container.
+
+TEST INFRASTRUCTURE.  The reference has no tests or golden vectors of its own
+(SURVEY.md section 4), so the oracle is pinned against outputs of the reference's
+unmodified modules executed here with seeded synthetic weights/inputs
+(sprc_amd/synth.py).  Only data (inputs/expected outputs) is written; no reference
+source travels.  Re-run with:  python oracle/gen_golden.py [--full]
+
+Files written:
+  tests/golden/tiny_eva.npz    ViT-g width, depth 2, 12-layer Q-Former : every stage boundary
+  tests/golden/tiny_clip.npz   ViT-L width, depth 2                    : every stage boundary
+  tests/golden/full_eva.npz    full depth (39 blocks), 2 images, 3 queries   (--full, ~3 min)
+  tests/golden/metrics.json    reference compute_cirr_val_metrics / compute_fiq_val_metrics /
+                               generate_cirr_test_dicts on synthetic sims (with engineered ties)
+  tests/golden/captions.json   reference BlipCaptionProcessor + FashionIQ caption composition
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.dont_write_bytecode = True
+
+from oracle import ref_import  # noqa: E402
+from sprc_amd import synth  # noqa: E402
+from sprc_amd.config import get_config  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+ROWS = [0, 1, 100, 256]          # token rows kept from [B,257,D] tensors (keeps fixtures small)
+
+
+def _np(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def model_goldens(model_type: str, vit_depth, n_img: int, n_q: int, out: Path, seed: int = 0):
+    cfg = get_config(model_type, vit_depth=vit_depth)
+    sd = synth.make_state_dict(cfg, seed=seed)
+    model = ref_import.build_reference_model(cfg, sd)
+    images = synth.make_images(n_img, seed=seed)
+    ids, mask, ref = synth.make_queries(n_q, n_img, seed=seed + 1)
+    ids[0, :] = 0                     # one fully padded-but-CLS caption: shortest legal text
+    ids[0, 0], ids[0, 1] = 101, 102
+    mask[0, :] = 0
+    mask[0, :2] = 1
+    taps = {}
+    vit = model.visual_encoder
+    hooks = []
+    if cfg.vit.kind == "eva_g":
+        hooks.append(vit.blocks[0].register_forward_pre_hook(lambda m, a: taps.__setitem__("patch_embed", a[0].clone())))
+        hooks.append(vit.blocks[0].register_forward_hook(lambda m, a, o: taps.__setitem__("block0", o.clone())))
+    else:
+        rb = vit.transformer.resblocks[0]   # LND layout inside the transformer (clip_vit.py:180-182)
+        hooks.append(rb.register_forward_pre_hook(lambda m, a: taps.__setitem__("patch_embed", a[0].permute(1, 0, 2).clone())))
+        hooks.append(rb.register_forward_hook(lambda m, a, o: taps.__setitem__("block0", o.permute(1, 0, 2).clone())))
+    with torch.no_grad():
+        vit_out = model.visual_encoder(images)
+        feats, raw = model.extract_target_features(images, mode="mean")
+        model.tokenizer.set_next(ids, mask)
+        q_taps = {}
+        bert = model.Qformer.bert
+        calls = []
+        h = bert.register_forward_hook(lambda m, a, k, o: calls.append(o.last_hidden_state.clone()), with_kwargs=True)
+        sim = model.inference(raw[ref], feats, ["caption"] * n_q)
+        h.remove()
+        # image-only Q-Former output (call shape (i))
+        img_q = bert(query_embeds=model.query_tokens.expand(n_img, -1, -1), encoder_hidden_states=raw,
+                     encoder_attention_mask=torch.ones(raw.shape[:-1], dtype=torch.long),
+                     return_dict=True).last_hidden_state
+        fusion = torch.nn.functional.normalize(model.text_proj(calls[1][:, 32, :]), dim=-1)
+    for hk in hooks:
+        hk.remove()
+    if sim.dim() == 1:
+        sim = sim.unsqueeze(0)
+    sample = {k: _np(v.flatten()[:8]) for k, v in list(sd.items())[:3]}
+    np.savez_compressed(
+        out,
+        model_type=model_type, vit_depth=cfg.vit.depth, seed=seed, n_img=n_img, n_q=n_q, rows=np.array(ROWS),
+        image_probe=_np(images[:, :, 0, :4]), weight_probe=np.concatenate(list(sample.values())),
+        patch_embed=_np(taps["patch_embed"][:, ROWS]), block0=_np(taps["block0"][:, ROWS]),
+        vit_out=_np(vit_out[:, ROWS]), raw=_np(raw[:, ROWS]), raw_full0=_np(raw[0]),
+        img_q=_np(img_q), feats=_np(feats),
+        input_ids=ids.numpy(), attention_mask=mask.numpy(), ref_index=ref.numpy(),
+        pass1=_np(calls[0]), pass2=_np(calls[1]), fusion=_np(fusion), sim=_np(sim),
+    )
+    print(f"wrote {out}  feats{tuple(feats.shape)} sim{tuple(sim.shape)}  sim range [{sim.min():.4f},{sim.max():.4f}]")
+
+
+# ------------------------------------------------------------------------------------------
+def _synthetic_retrieval(nq: int, N: int, seed: int, ties: bool):
+    rng = np.random.default_rng(seed)
+    sim = rng.uniform(-0.2, 0.9, size=(nq, N)).astype(np.float32)
+    if ties:   # coarse grid -> many exact ties in fl32(1 - sim), incl. around the target
+        sim = (np.round(sim * 16) / 16).astype(np.float32)
+    names = [f"img-{i:05d}" for i in range(N)]
+    ref = rng.integers(0, N, size=nq)
+    tgt = (ref + 1 + rng.integers(0, N - 1, size=nq)) % N
+    groups = np.zeros((nq, 6), dtype=np.int64)
+    for q in range(nq):
+        others = [i for i in rng.permutation(N) if i != ref[q] and i != tgt[q]][:4]
+        g = np.array([ref[q], tgt[q], *others])
+        groups[q] = rng.permutation(g)
+    return sim, names, ref, tgt, groups
+
+
+def metrics_goldens(out: Path):
+    vb, cts = ref_import.import_harness()
+    from torch.utils.data import Dataset
+
+    class FakeModel:
+        device = torch.device("cpu")
+
+        def __init__(self, sim):
+            self.sim = torch.from_numpy(sim)
+
+        def inference(self, reference_embeds, target_feats, captions):
+            rows = [int(c[1:]) for c in captions]
+            return self.sim[rows]
+
+    class CirrVal(Dataset):
+        def __init__(self, names, ref, tgt, groups):
+            self.names, self.ref, self.tgt, self.groups = names, ref, tgt, groups
+
+        def __len__(self):
+            return len(self.ref)
+
+        def __getitem__(self, i):
+            return (self.names[self.ref[i]], self.names[self.tgt[i]], f"q{i}",
+                    [self.names[g] for g in self.groups[i]])
+
+    class CirrTest(CirrVal):
+        def __getitem__(self, i):
+            return (1000 + i, self.names[self.ref[i]], f"q{i}", [self.names[g] for g in self.groups[i]])
+
+    class FiqVal(CirrVal):
+        dress_types = ["dress"]
+
+        def __getitem__(self, i):     # captions: two strings; the fake processor recovers the index
+            return self.names[self.ref[i]], self.names[self.tgt[i]], [f"q{i}", "x"]
+
+    txt = {"eval": lambda c: c}
+    cases = {}
+    for name, nq, N, seed, ties in [("plain", 70, 97, 0, False), ("ties", 70, 97, 1, True),
+                                    ("single_batch", 5, 60, 2, True)]:
+        sim, names, ref, tgt, groups = _synthetic_retrieval(nq, N, seed, ties)
+        fm = FakeModel(sim)
+        feats = (torch.zeros(N, 1), torch.zeros(N, 1))
+        cirr = vb.compute_cirr_val_metrics(CirrVal(names, ref, tgt, groups), fm, feats, names, txt)
+        # FashionIQ path builds "{Cap1} and {cap2}" -> "Q<i> and x"; map it back to q<i>
+        fiq_txt = {"eval": lambda c: "q" + c.split(" ")[0][1:]}
+        fiq = vb.compute_fiq_val_metrics(FiqVal(names, ref, tgt, groups), fm, feats, names, fiq_txt)
+        top, sub = cts.generate_cirr_test_dicts(CirrTest(names, ref, tgt, groups), fm, feats, names, txt, False)
+        cases[name] = dict(nq=nq, N=N, seed=seed, ties=ties,
+                           sim=sim.tolist(), ref=ref.tolist(), tgt=tgt.tolist(), groups=groups.tolist(),
+                           cirr=list(cirr), fiq=list(fiq), test_top50=top, test_subset3=sub)
+        print(name, "cirr", [round(x, 3) for x in cirr], "fiq", fiq)
+    out.write_text(json.dumps(cases))
+    print("wrote", out)
+
+
+def caption_goldens(out: Path):
+    import importlib
+    import types
+    ref_import.install_shims()
+    # blip_processors imports torchvision/omegaconf/randaugment at module level; only the pure-string
+    # BlipCaptionProcessor is exercised.
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+    tf = types.ModuleType("torchvision.transforms.functional")
+    tf.InterpolationMode = types.SimpleNamespace(BICUBIC=3)
+    tr.functional = tf
+    tr.Normalize = lambda *a, **k: None
+    tv.transforms = tr
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.transforms.functional": tf})
+    sys.modules["lavis.processors.randaugment"] = types.SimpleNamespace(RandomAugment=object)
+    base = importlib.import_module("lavis.processors.base_processor")
+    sys.modules["lavis.processors"].BaseProcessor = base.BaseProcessor        # registry.py:124
+    bp = importlib.import_module("lavis.processors.blip_processors")
+    proc = bp.BlipCaptionProcessor()
+    raw = [
+        "Make the dog bigger.", "  Remove the \"second\" person (left)!  ", "A*B#C:D;E~F", "trailing newline\n",
+        "multiple     spaces   here", "UPPER Case And Punctuation!!!", "", "x", " ".join(f"w{i}" for i in range(70)),
+        "is shorter.?, ", "has a v-neck; and it's (more) colourful", "Shows two dogs instead of one: both brown.",
+    ]
+    table = [[c, proc(c)] for c in raw]
+    pairs = [["is shorter.", "has longer sleeves"], ["Is Red?", "  and blue,"], ["more colorful.", "less formal. "]]
+    fiq = []
+    for c1, c2 in pairs:   # validate_blip.py:180-184 composition, executed here as the reference writes it
+        flattened = [c1, c2]
+        composed = f"{flattened[0].strip('.?, ').capitalize()} and {flattened[1].strip('.?, ')}"
+        fiq.append([c1, c2, composed, proc(composed)])
+    out.write_text(json.dumps({"pre_caption": table, "fiq": fiq}, indent=1))
+    print("wrote", out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also generate the full-depth ViT-g golden (slow)")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    GOLD.mkdir(parents=True, exist_ok=True)
+    torch.set_num_threads(8)
+    only = set(a.only.split(",")) if a.only else None
+
+    def want(k):
+        return only is None or k in only
+
+    if want("captions"):
+        caption_goldens(GOLD / "captions.json")
+    if want("metrics"):
+        metrics_goldens(GOLD / "metrics.json")
+    if want("tiny_eva"):
+        model_goldens("pretrain", 2, n_img=4, n_q=6, out=GOLD / "tiny_eva.npz")
+    if want("tiny_clip"):
+        model_goldens("pretrain_vitL", 2, n_img=3, n_q=4, out=GOLD / "tiny_clip.npz")
+    if a.full and want("full_eva"):
+        model_goldens("pretrain", None, n_img=2, n_q=3, out=GOLD / "full_eva.npz")
+
+
+if __name__ == "__main__":
+    main()

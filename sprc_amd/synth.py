@@ -1,0 +1,161 @@
+"""Deterministic synthetic checkpoints and inputs.
+
+The reference's weights (eva_vit_g.pth, blip2_pretrained.pth, sprc_cirr.pt) are
+network fetches (models/eva_vit.py:442-446, configs/models/blip2/blip2_pretrain.yaml:10,
+README.md:123-128) and are not available offline, so parity and benchmark runs use
+seeded random state dicts with the reference's own key names and shapes
+(SURVEY.md section 8(b)).  Each tensor is drawn from its own torch CPU generator
+seeded by crc32(name) so that any subset of tensors can be produced independently
+and identically in the golden-vector script, the oracle and the HIP engine.
+
+Synthetic inputs follow SURVEY.md section 8(d): images ~ N(0,1) (the distribution of
+CLIP-normalised pixels), captions as ``input_ids[nq,32]`` with [CLS]=101 at column 0,
+uniform ids in [1000,30000), length U{4..32}, [SEP]=102 at the last real column,
+0 padding; the reference image of query i is gallery index (7919*i) mod N.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Iterator, List, Tuple
+
+import torch
+
+from .config import SprcConfig
+
+Spec = Tuple[str, Tuple[int, ...], str]
+
+
+def _vit_specs(cfg: SprcConfig) -> List[Spec]:
+    v = cfg.vit
+    D, F, T = v.width, v.mlp, v.tokens
+    p = "visual_encoder."
+    out: List[Spec] = []
+    if v.kind == "eva_g":
+        out += [(p + "cls_token", (1, 1, D), "emb"), (p + "pos_embed", (1, T, D), "emb"),
+                (p + "patch_embed.proj.weight", (D, 3, v.patch, v.patch), "w"),
+                (p + "patch_embed.proj.bias", (D,), "b")]
+        for i in range(v.depth):
+            b = f"{p}blocks.{i}."
+            out += [(b + "norm1.weight", (D,), "ln_w"), (b + "norm1.bias", (D,), "ln_b"),
+                    (b + "attn.q_bias", (D,), "b"), (b + "attn.v_bias", (D,), "b"),
+                    (b + "attn.qkv.weight", (3 * D, D), "w"),
+                    (b + "attn.proj.weight", (D, D), f"w_res{i + 1}"), (b + "attn.proj.bias", (D,), "b"),
+                    (b + "norm2.weight", (D,), "ln_w"), (b + "norm2.bias", (D,), "ln_b"),
+                    (b + "mlp.fc1.weight", (F, D), "w"), (b + "mlp.fc1.bias", (F,), "b"),
+                    (b + "mlp.fc2.weight", (D, F), f"w_res{i + 1}"), (b + "mlp.fc2.bias", (D,), "b")]
+    elif v.kind == "clip_L":
+        out += [(p + "class_embedding", (D,), "emb"), (p + "positional_embedding", (T, D), "emb"),
+                (p + "conv1.weight", (D, 3, v.patch, v.patch), "w"),
+                (p + "ln_pre.weight", (D,), "ln_w"), (p + "ln_pre.bias", (D,), "ln_b")]
+        for i in range(v.depth):
+            b = f"{p}transformer.resblocks.{i}."
+            out += [(b + "ln_1.weight", (D,), "ln_w"), (b + "ln_1.bias", (D,), "ln_b"),
+                    (b + "attn.in_proj_weight", (3 * D, D), "w"), (b + "attn.in_proj_bias", (3 * D,), "b"),
+                    (b + "attn.out_proj.weight", (D, D), f"w_res{i + 1}"), (b + "attn.out_proj.bias", (D,), "b"),
+                    (b + "ln_2.weight", (D,), "ln_w"), (b + "ln_2.bias", (D,), "ln_b"),
+                    (b + "mlp.c_fc.weight", (F, D), "w"), (b + "mlp.c_fc.bias", (F,), "b"),
+                    (b + "mlp.c_proj.weight", (D, F), f"w_res{i + 1}"), (b + "mlp.c_proj.bias", (D,), "b")]
+    else:
+        raise ValueError(v.kind)
+    return out
+
+
+def _qformer_specs(cfg: SprcConfig) -> List[Spec]:
+    q = cfg.qformer
+    H, F, Dv = q.hidden, q.ffn, cfg.vit.width
+    p = "Qformer.bert."
+    out: List[Spec] = [
+        (p + "embeddings.word_embeddings.weight", (q.vocab, H), "emb"),
+        (p + "embeddings.position_embeddings.weight", (q.max_pos, H), "emb"),
+        (p + "embeddings.LayerNorm.weight", (H,), "ln_w"), (p + "embeddings.LayerNorm.bias", (H,), "ln_b"),
+    ]
+
+    def attn(prefix: str, kv_in: int) -> List[Spec]:
+        return [(prefix + "self.query.weight", (H, H), "w"), (prefix + "self.query.bias", (H,), "b"),
+                (prefix + "self.key.weight", (H, kv_in), "w"), (prefix + "self.key.bias", (H,), "b"),
+                (prefix + "self.value.weight", (H, kv_in), "w"), (prefix + "self.value.bias", (H,), "b"),
+                (prefix + "output.dense.weight", (H, H), "w"), (prefix + "output.dense.bias", (H,), "b"),
+                (prefix + "output.LayerNorm.weight", (H,), "ln_w"), (prefix + "output.LayerNorm.bias", (H,), "ln_b")]
+
+    def ffn(prefix_i: str, prefix_o: str) -> List[Spec]:
+        return [(prefix_i + "dense.weight", (F, H), "w"), (prefix_i + "dense.bias", (F,), "b"),
+                (prefix_o + "dense.weight", (H, F), "w"), (prefix_o + "dense.bias", (H,), "b"),
+                (prefix_o + "LayerNorm.weight", (H,), "ln_w"), (prefix_o + "LayerNorm.bias", (H,), "ln_b")]
+
+    for l in range(q.layers):
+        b = f"{p}encoder.layer.{l}."
+        out += attn(b + "attention.", H)
+        if l % q.cross_freq == 0:                       # Qformer.py:392-399
+            out += attn(b + "crossattention.", Dv)
+        out += ffn(b + "intermediate.", b + "output.")
+        out += ffn(b + "intermediate_query.", b + "output_query.")
+    return out
+
+
+def param_specs(cfg: SprcConfig) -> List[Spec]:
+    """(state-dict key, shape, init kind) for every tensor the retrieval path reads."""
+    H, E, Dv = cfg.qformer.hidden, cfg.embed_dim, cfg.vit.width
+    out = _vit_specs(cfg)
+    out += [("ln_vision.weight", (Dv,), "ln_w"), ("ln_vision.bias", (Dv,), "ln_b"),
+            ("query_tokens", (1, cfg.qformer.num_query, H), "emb"),
+            ("prompt_tokens", (1, cfg.qformer.num_query, H), "emb")]
+    out += _qformer_specs(cfg)
+    out += [("vision_proj.weight", (E, H), "w_head"), ("vision_proj.bias", (E,), "b"),
+            ("text_proj.weight", (E, H), "w_head"), ("text_proj.bias", (E,), "b")]
+    return out
+
+
+def _draw(name: str, shape: Tuple[int, ...], kind: str, seed: int, device: str) -> torch.Tensor:
+    if device == "cpu":
+        g = torch.Generator(device="cpu")
+        g.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+        x = torch.randn(shape, generator=g, dtype=torch.float32)
+    else:  # throughput runs only: fast on-device fill, not reproducible against the CPU draw
+        g = torch.Generator(device=device)
+        g.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+        x = torch.randn(shape, generator=g, dtype=torch.float32, device=device)
+    if kind == "w" or kind == "emb":
+        return x.mul_(0.02)
+    if kind == "w_head":
+        return x.mul_(0.05)
+    if kind.startswith("w_res"):           # eva_vit.py:297-303 rescales proj/fc2 by 1/sqrt(2*layer_id)
+        return x.mul_(0.02 / (2.0 * int(kind[5:])) ** 0.5)
+    if kind == "b" or kind == "ln_b":
+        return x.mul_(0.02)
+    if kind == "ln_w":
+        return x.mul_(0.1).add_(1.0)
+    raise ValueError(kind)
+
+
+def iter_state_dict(cfg: SprcConfig, seed: int = 0, device: str = "cpu") -> Iterator[Tuple[str, torch.Tensor]]:
+    for name, shape, kind in param_specs(cfg):
+        yield name, _draw(name, shape, kind, seed, device)
+
+
+def make_state_dict(cfg: SprcConfig, seed: int = 0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Seeded random state dict with the reference's key names (fp32)."""
+    sd = dict(iter_state_dict(cfg, seed, device))
+    sd["temp"] = torch.tensor(0.07, device=device)          # align_prompt.py:84 (unused by inference)
+    return sd
+
+
+def make_images(n: int, seed: int = 0, image: int = 224) -> torch.Tensor:
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    return torch.randn((n, 3, image, image), generator=g, dtype=torch.float32)
+
+
+def make_queries(nq: int, n_gallery: int, seed: int = 1, max_len: int = 32,
+                 vocab_lo: int = 1000, vocab_hi: int = 30000):
+    """Synthetic tokenised captions + the gallery index of each query's reference image."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    ids = torch.randint(vocab_lo, vocab_hi, (nq, max_len), generator=g, dtype=torch.int64)
+    lens = torch.randint(4, max_len + 1, (nq,), generator=g, dtype=torch.int64)
+    col = torch.arange(max_len).unsqueeze(0)
+    mask = (col < lens.unsqueeze(1)).to(torch.int64)
+    ids = ids * mask
+    ids[:, 0] = 101
+    ids[torch.arange(nq), lens - 1] = 102
+    ref_index = (7919 * torch.arange(nq, dtype=torch.int64)) % max(n_gallery, 1)
+    return ids, mask, ref_index

@@ -1,0 +1,22 @@
+"""pytest configuration: marker registration + shared fixtures."""
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+sys.dont_write_bytecode = True
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: full-depth CPU oracle runs")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

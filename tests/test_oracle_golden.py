@@ -1,0 +1,128 @@
+"""The CPU oracle (oracle/sprc_oracle.py) against outputs of the REFERENCE itself.
+
+tests/golden/*.npz|json were produced by oracle/gen_golden.py, which imports and runs the
+unmodified reference modules in the build container (R1-R8, R10).  These tests pin the oracle.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sprc_oracle as O
+from sprc_amd import synth
+from sprc_amd.config import get_config
+
+TOL = 2e-5     # fp32 round-off between two CPU evaluations of the same graph
+
+
+def _load(golden_dir, name):
+    g = np.load(golden_dir / name, allow_pickle=False)
+    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]))
+    # the synthetic generators must reproduce what the golden script saw
+    np.testing.assert_array_equal(images[:, :, 0, :4].numpy(), g["image_probe"])
+    probe = np.concatenate([v.flatten()[:8].numpy() for v in list(sd.values())[:3]])
+    np.testing.assert_array_equal(probe, g["weight_probe"])
+    return g, cfg, sd, images
+
+
+@pytest.mark.parametrize("name", ["tiny_eva.npz", "tiny_clip.npz"])
+def test_model_stages_match_reference(golden_dir, name):
+    g, cfg, sd, images = _load(golden_dir, name)
+    rows = g["rows"].tolist()
+    taps = {}
+    with torch.no_grad():
+        feats, raw = O.extract_target_features(sd, cfg, images, taps=taps)
+        vit_out = O.vit_forward(sd, cfg, images)
+        img_q = O.qformer_forward(sd, cfg, sd["query_tokens"].expand(images.shape[0], -1, -1),
+                                  encoder_hidden_states=raw)
+    np.testing.assert_allclose(taps["patch_embed"][:, rows].numpy(), g["patch_embed"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(taps["block0"][:, rows].numpy(), g["block0"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(vit_out[:, rows].numpy(), g["vit_out"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(raw[:, rows].numpy(), g["raw"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(raw[0].numpy(), g["raw_full0"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(img_q.numpy(), g["img_q"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(feats.numpy(), g["feats"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(np.linalg.norm(feats.numpy(), axis=-1), 1.0, atol=1e-5)
+
+    ids = torch.from_numpy(g["input_ids"])
+    mask = torch.from_numpy(g["attention_mask"])
+    ref = torch.from_numpy(g["ref_index"])
+    t2 = {}
+    with torch.no_grad():
+        sim = O.inference(sd, cfg, raw[ref], feats, ids, mask, taps=t2)
+    np.testing.assert_allclose(t2["pass1"].numpy(), g["pass1"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(t2["pass2"].numpy(), g["pass2"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(t2["fusion"].numpy(), g["fusion"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(sim.numpy(), g["sim"], atol=TOL, rtol=0)
+
+
+@pytest.mark.slow
+def test_full_depth_matches_reference(golden_dir):
+    path = golden_dir / "full_eva.npz"
+    if not path.exists():
+        pytest.skip("full-depth golden not generated")
+    g, cfg, sd, images = _load(golden_dir, "full_eva.npz")
+    with torch.no_grad():
+        feats, raw = O.extract_target_features(sd, cfg, images)
+        sim = O.inference(sd, cfg, raw[torch.from_numpy(g["ref_index"])], feats,
+                          torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]))
+    np.testing.assert_allclose(feats.numpy(), g["feats"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(raw[:, g["rows"].tolist()].numpy(), g["raw"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(sim.numpy(), g["sim"], atol=5e-5, rtol=0)
+
+
+def _valid_order(sim_row, order):
+    """`order` sorts fl32(1-sim) ascending (any tie order)."""
+    d = O.distances(sim_row[None])[0]
+    return np.all(np.diff(d[order]) >= 0)
+
+
+@pytest.mark.parametrize("case", ["plain", "ties", "single_batch"])
+def test_metrics_match_reference(golden_dir, case):
+    c = json.loads((golden_dir / "metrics.json").read_text())[case]
+    sim = np.asarray(c["sim"], dtype=np.float32)
+    ref, tgt, groups = np.asarray(c["ref"]), np.asarray(c["tgt"]), np.asarray(c["groups"])
+    names = [f"img-{i:05d}" for i in range(c["N"])]
+    got = O.cirr_metrics(sim, ref, tgt, groups)
+    fiq = O.fiq_metrics(sim, tgt)
+    top, sub = O.cirr_test_dicts(sim, ref, groups, [1000 + i for i in range(c["nq"])], names)
+    if not c["ties"]:
+        np.testing.assert_allclose(got, c["cirr"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(fiq, c["fiq"], rtol=0, atol=1e-4)
+        assert top == c["test_top50"] and sub == c["test_subset3"]
+    else:
+        # torch.argsort in the reference is unstable: with engineered ties the reference's order is
+        # ONE valid order, the contract's stable order another.  Both must sort the same distances,
+        # so the sorted distance sequences agree position by position.
+        name_to_i = {n: i for i, n in enumerate(names)}
+        d = O.distances(sim)
+        for q, (pid, ref_top) in enumerate(sorted(c["test_top50"].items(), key=lambda kv: int(kv[0]))):
+            mine = top[pid]
+            a = d[q, [name_to_i[n] for n in ref_top]]
+            b = d[q, [name_to_i[n] for n in mine]]
+            np.testing.assert_array_equal(a, b)
+        # recall differs from the reference's only through ties straddling K or involving the target
+        assert np.all(np.abs(np.asarray(got) - np.asarray(c["cirr"])) <= 100.0 * 8 / c["nq"])
+
+
+def test_rank_of_is_position_in_stable_order():
+    rng = np.random.default_rng(3)
+    sim = (np.round(rng.uniform(0, 1, (9, 40)) * 8) / 8).astype(np.float32)
+    order = O.rank_stable(sim)
+    listed = rng.integers(0, 40, (9, 5))
+    r = O.rank_of(sim, listed)
+    for q in range(9):
+        for l in range(5):
+            assert order[q, r[q, l]] == listed[q, l]
+
+
+def test_caption_processing_matches_reference(golden_dir):
+    c = json.loads((golden_dir / "captions.json").read_text())
+    for raw, want in c["pre_caption"]:
+        assert O.pre_caption(raw) == want
+    for c1, c2, composed, processed in c["fiq"]:
+        assert O.fiq_caption(c1, c2) == composed
+        assert O.pre_caption(composed) == processed
