@@ -1,0 +1,215 @@
+/* sprc.h -- C ABI of the MI355X-native SPRC retrieval engine (libsprc_hip.so).
+ *
+ * The reference (chunmeifeng/SPRC) is pure Python and has no FFI; its "plugin API" is the
+ * duck-typed model protocol consumed by its evaluation harness.
+ * Every entry point below names the reference call site(s) whose computation it replaces
+ * (paths relative to /root/reference/src).  The Python host (sprc_amd/model.py) mirrors the
+ * reference protocol (`extract_target_features`, `inference`) and binds these symbols with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch types: raw device pointers, explicit sizes, a stream handle
+ *     (hipStream_t passed as void*; the caller's current stream);
+ *   - the caller owns every input, output and workspace buffer; the library never allocates
+ *     or frees device memory and never synchronises the stream;
+ *   - return 0 on success, a negative SPRC_E* code otherwise; sprc_last_error() returns a
+ *     thread-local message; no C++ exception crosses the boundary;
+ *   - all matrices are row-major; "ld*" are leading dimensions in ELEMENTS;
+ *   - compute dtype: SPRC_BF16 (bf16 MFMA operands, fp32 accumulate, fp32 residual stream /
+ *     LayerNorm / softmax) or SPRC_F32 (exact fp32 MFMA, parity mode).
+ */
+#ifndef SPRC_H
+#define SPRC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPRC_ABI_VERSION 1
+
+enum { SPRC_OK = 0, SPRC_EINVAL = -1, SPRC_ELAUNCH = -2, SPRC_EWORKSPACE = -3, SPRC_EUNSUPPORTED = -4 };
+enum { SPRC_F32 = 0, SPRC_BF16 = 1 };
+enum { SPRC_ACT_NONE = 0, SPRC_ACT_GELU = 1, SPRC_ACT_QUICKGELU = 2 };
+
+typedef void* sprc_stream;                    /* hipStream_t */
+
+/* Row indirection shared by GEMM / LayerNorm: logical row m lives at physical row
+ *   (m / rows_per_group) * group_stride + (m % rows_per_group) + group_offset
+ * (rows_per_group == 0 -> identity).  Lets the Q-Former address "rows [:32]" / "rows [32:]" of a
+ * [B,64,768] tensor (Qformer.py:436,455-468) without copies. */
+typedef struct { int32_t rows_per_group, group_stride, group_offset; } sprc_rowmap;
+
+/* ------------------------------------------------------------------------------------------
+ * Building-block operators (also what the unit parity tests drive)
+ * ---------------------------------------------------------------------------------------- */
+
+int         sprc_version(void);
+const char* sprc_last_error(void);
+
+/* fp32 -> bf16 (round-to-nearest-even) weight/feature packing. */
+int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s);
+
+/* C = epilogue(A[M,K] . W[N,K]^T + bias) -- replaces every nn.Linear / F.linear on the path:
+ * eva_vit.py:123,146,55-60; clip_vit.py:132-139; Qformer.py:135-137,201-211,291-293,365,377;
+ * align_prompt.py:348,385.  A and W are `dtype`; bias/resid fp32; out is `out_dtype`.
+ * K % 64 == 0 (bf16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (bf16) / 4 (f32) elements.
+ *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
+ * max32 != 0: "similarity" epilogue -- rows of A are gallery tokens (32 per image), rows of W are
+ * query vectors; out[n*ldc + m/32] = max over the 32 rows of image m/32 (align_prompt.py:353-358). */
+typedef struct {
+    int32_t M, N, K;
+    int32_t dtype, out_dtype, act, max32;
+    const void* A;  int64_t lda;  sprc_rowmap amap;
+    const void* W;  int64_t ldw;
+    const float* bias;
+    const float* resid; int64_t ldr;
+    void* C;        int64_t ldc;  sprc_rowmap cmap;
+} sprc_gemm_args;
+int sprc_gemm(const sprc_gemm_args* a, sprc_stream s);
+
+/* y = LayerNorm(x) over the last dim (fp32 statistics, two-pass) -- nn.LayerNorm at
+ * eva_vit.py:175-176 (eps 1e-6), clip_vit.py:100-106, blip2.py:193-199 (ln_vision, eps 1e-5),
+ * Qformer.py:112,294,380 (eps 1e-12).  Writes an fp32 copy (residual stream) and/or a
+ * compute-dtype copy (next GEMM operand); either may be NULL. */
+typedef struct {
+    int32_t M, D, out_dtype;
+    const float* x;  int64_t ldx;  sprc_rowmap xmap;
+    const float* gamma; const float* beta; float eps;
+    float* y32;      int64_t ld32; sprc_rowmap ymap;
+    void*  y16;      int64_t ld16;              /* rows mapped with ymap as well */
+} sprc_layernorm_args;
+int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s);
+
+/* out = softmax(scale * Q K^T + key_mask) V per (batch, head) -- eva_vit.py:128-145,
+ * nn.MultiheadAttention in clip_vit.py:132-134, Qformer.py:233-268.  Q/K/V/out are `dtype`
+ * (bf16 or f32); token t of batch b, head h, lives at  ptr + (b*T + t)*ld + h*head_dim.
+ * key_mask: optional additive fp32 [B,Tk] (Qformer.py:806-807: (1-m)*-10000). */
+typedef struct {
+    int32_t B, H, Tq, Tk, head_dim, dtype;
+    const void* q; int64_t ldq;
+    const void* k; int64_t ldk;
+    const void* v; int64_t ldv;
+    void* out;     int64_t ldo;
+    const float* key_mask;
+    float scale;
+} sprc_attention_args;
+int sprc_attention(const sprc_attention_args* a, sprc_stream s);
+
+/* Patch extraction for the 14x14/stride-14 conv (eva_vit.py:196,203; clip_vit.py:160,173-175):
+ * images [B,3,S,S] fp32 -> rows [B*G*G, k_pad] (`dtype`), column = c*P*P + i*P + j, zero padded. */
+int sprc_im2row(const float* images, void* rows, int32_t B, int32_t image, int32_t patch, int32_t k_pad,
+                int32_t dtype, sprc_stream s);
+
+/* x[b,0,:] = cls + pos[0];  x[b,1+p,:] = patch_out[b,p,:] + pos[1+p]
+ * (eva_vit.py:328-331; clip_vit.py:176-177).  fp32. */
+int sprc_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x,
+                      int32_t B, int32_t tokens, int32_t width, sprc_stream s);
+
+/* Q-Former embeddings (Qformer.py:98-114): rows [0,Lq) = query_embeds (batch stride q_bstride, 0 =
+ * broadcast), rows [Lq,Lq+Lt) = word_emb[ids] + pos_emb[0..Lt); one LayerNorm over all rows.
+ * input_ids may be NULL (Lt = 0).  Writes fp32 and compute-dtype copies. */
+typedef struct {
+    int32_t B, Lq, Lt, hidden, out_dtype;
+    const float* query_embeds; int64_t q_bstride;
+    const int64_t* input_ids;
+    const float* word_emb; const float* pos_emb;
+    const float* gamma; const float* beta; float eps;
+    float* y32; void* y16;                      /* [B, Lq+Lt, hidden] contiguous */
+} sprc_qformer_embed_args;
+int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream s);
+
+/* y = x / max(||x||_2, 1e-12) per row (F.normalize, align_prompt.py:348-350,385). */
+int sprc_l2norm_rows(const float* x, int64_t ldx, float* y32, void* y16, int64_t ldy, int32_t M, int32_t D,
+                     int32_t out_dtype, sprc_stream s);
+
+/* additive key mask (Qformer.py:806-807): out[b, j] = j < Lq ? 0 : (1 - mask[b, j-Lq]) * -10000 */
+int sprc_qformer_mask(const int64_t* attention_mask, float* out, int32_t B, int32_t Lq, int32_t Lt, sprc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Ranking (R7): validate_blip.py:253-254, :44-45; cirr_test_submission.py:82-83
+ * ---------------------------------------------------------------------------------------- */
+
+/* sim[nq,N] = max_j <fusion[q,:], feats[n,j,:]>  (align_prompt.py:353-358) -- thin wrapper over
+ * sprc_gemm(max32).  fusion [nq,E], feats [N,J=32,E], both `dtype`. */
+int sprc_sim_max(const void* fusion, const void* feats, float* sim, int64_t ld_sim,
+                 int32_t nq, int32_t N, int32_t E, int32_t dtype, sprc_stream s);
+
+/* Per row of sim[nq,N] (ld in elements): the k smallest keys (fl32(1 - sim[n]), gidx[n]) ascending,
+ * i.e. the first k entries of a STABLE argsort of the fp32 distance (the ranking contract,
+ * SURVEY.md section 7).  gidx: optional int32 [nq,N] global indices (NULL -> n + idx_base).
+ * out_sim [nq,k] fp32, out_idx [nq,k] int32; unused slots (N < k) get sim = -inf, idx = -1.
+ * 1 <= k <= 64. */
+int sprc_topk(const float* sim, int64_t ld, const int32_t* gidx, int32_t idx_base,
+              int32_t nq, int32_t N, int32_t k, float* out_sim, int32_t* out_idx, sprc_stream s);
+
+/* rank[q,l] = #{ n : (d[q,n], n) < (d[q,t], t) },  t = listed[q,l]  (-1 where t < 0): the position
+ * of gallery item t in the stable order, without sorting (exact Recall@K for any K). */
+int sprc_rank_of(const float* sim, int64_t ld, const int32_t* listed, int32_t nq, int32_t N, int32_t L,
+                 int32_t* rank, sprc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Composite forward passes (one call per batch; the kernels above, sequenced on `s`)
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct { const void* w; const float* b; } sprc_linear;   /* w: [out,in(padded)] compute dtype */
+
+typedef struct {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    sprc_linear qkv, proj, fc1, fc2;            /* qkv bias: [q_bias, 0, v_bias] (eva_vit.py:120-122) */
+} sprc_vit_layer;
+
+typedef struct {
+    int32_t dtype, width, depth, heads, head_dim, mlp, act, tokens, patch_size, image, patch_k_pad, has_ln_pre;
+    float ln_eps, ln_vision_eps;
+    sprc_linear patch;                          /* [width, patch_k_pad]; bias may be NULL (clip) */
+    const float *cls, *pos;                     /* [width], [tokens,width] */
+    const float *ln_pre_w, *ln_pre_b, *ln_vision_w, *ln_vision_b;
+    const sprc_vit_layer* layers;               /* host array [depth] */
+} sprc_vit_model;
+
+typedef struct {
+    sprc_linear qkv, attn_out;        const float *attn_ln_w, *attn_ln_b;
+    int32_t has_cross, cross_index;   /* cross_index: position of this layer's K|V block in ckv_all */
+    sprc_linear cq, cross_out;        const float *cross_ln_w, *cross_ln_b;
+    sprc_linear ffn_t_in, ffn_t_out;  const float *ffn_t_ln_w, *ffn_t_ln_b;
+    sprc_linear ffn_q_in, ffn_q_out;  const float *ffn_q_ln_w, *ffn_q_ln_b;
+} sprc_qf_layer;
+
+typedef struct {
+    int32_t dtype, hidden, n_layers, heads, head_dim, ffn, num_query, enc_width, embed_dim, max_txt, n_cross;
+    float ln_eps;
+    const float *word_emb, *pos_emb, *emb_ln_w, *emb_ln_b;
+    const float* query_tokens;                  /* [num_query, hidden] */
+    sprc_linear ckv_all;                        /* [n_cross*2*hidden, enc_width]: K|V of every cross layer */
+    sprc_linear vision_proj, text_proj;         /* [embed_dim, hidden] */
+    const sprc_qf_layer* layers;                /* host array [n_layers] */
+} sprc_qformer_model;
+
+/* Workspace sizes in bytes for a batch of B (images or queries). */
+size_t sprc_vit_workspace_bytes(const sprc_vit_model* m, int32_t B);
+size_t sprc_qformer_workspace_bytes(const sprc_qformer_model* m, int32_t B);
+
+/* raw[B,tokens,width] (fp32) = ln_vision(ViT(images[B,3,S,S]))   -- align_prompt.py:366-368,
+ * eva_vit.py:324-340 / clip_vit.py:171-185, blip2.py:193-199. */
+int sprc_vit_forward(const sprc_vit_model* m, const float* images, int32_t B, float* raw,
+                     void* ws, size_t ws_bytes, sprc_stream s);
+
+/* feats[B,32,E] = normalize(vision_proj(Qformer(query_tokens, enc = raw)))  -- align_prompt.py:369-385;
+ * Q-Former call shape (i).  feats16 (optional) receives the compute-dtype copy for bf16 ranking. */
+int sprc_qformer_image(const sprc_qformer_model* m, const float* raw, int32_t B, float* feats, void* feats16,
+                       void* ws, size_t ws_bytes, sprc_stream s);
+
+/* fusion[B,E] = normalize(text_proj(pass2[:,32,:]))  -- align_prompt.py:313-350: Q-Former pass 1
+ * (ids + reference image, call shape (ii)) then pass 2 (call shape (iii)).
+ * ref_embeds [B,tokens,enc_width] fp32, input_ids/attention_mask [B,max_txt] int64. */
+int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
+                      const int64_t* input_ids, const int64_t* attention_mask, int32_t B,
+                      float* fusion, void* fusion16, void* ws, size_t ws_bytes, sprc_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPRC_H */

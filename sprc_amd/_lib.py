@@ -1,0 +1,130 @@
+"""ctypes binding of libsprc_hip.so (include/sprc.h).
+
+The library is the only compute path of the product: there is no CPU fallback.  `load()`
+raises if the shared object is missing (build it with `python -m sprc_amd.build`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libsprc_hip.so"
+
+SPRC_F32, SPRC_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
+DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16}
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class RowMap(C.Structure):
+    _fields_ = [("rows_per_group", i32), ("group_stride", i32), ("group_offset", i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("dtype", i32), ("out_dtype", i32), ("act", i32), ("max32", i32),
+                ("A", vp), ("lda", i64), ("amap", RowMap), ("W", vp), ("ldw", i64), ("bias", vp),
+                ("resid", vp), ("ldr", i64), ("C", vp), ("ldc", i64), ("cmap", RowMap)]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [("M", i32), ("D", i32), ("out_dtype", i32), ("x", vp), ("ldx", i64), ("xmap", RowMap),
+                ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("ld32", i64), ("ymap", RowMap),
+                ("y16", vp), ("ld16", i64)]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("head_dim", i32), ("dtype", i32),
+                ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64), ("out", vp), ("ldo", i64),
+                ("key_mask", vp), ("scale", f32)]
+
+
+class QformerEmbedArgs(C.Structure):
+    _fields_ = [("B", i32), ("Lq", i32), ("Lt", i32), ("hidden", i32), ("out_dtype", i32),
+                ("query_embeds", vp), ("q_bstride", i64), ("input_ids", vp), ("word_emb", vp), ("pos_emb", vp),
+                ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("y16", vp)]
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", vp), ("b", vp)]
+
+
+class VitLayer(C.Structure):
+    _fields_ = [("ln1_w", vp), ("ln1_b", vp), ("ln2_w", vp), ("ln2_b", vp),
+                ("qkv", Linear), ("proj", Linear), ("fc1", Linear), ("fc2", Linear)]
+
+
+class VitModel(C.Structure):
+    _fields_ = [("dtype", i32), ("width", i32), ("depth", i32), ("heads", i32), ("head_dim", i32), ("mlp", i32),
+                ("act", i32), ("tokens", i32), ("patch_size", i32), ("image", i32), ("patch_k_pad", i32),
+                ("has_ln_pre", i32), ("ln_eps", f32), ("ln_vision_eps", f32), ("patch", Linear),
+                ("cls", vp), ("pos", vp), ("ln_pre_w", vp), ("ln_pre_b", vp), ("ln_vision_w", vp), ("ln_vision_b", vp),
+                ("layers", C.POINTER(VitLayer))]
+
+
+class QfLayer(C.Structure):
+    _fields_ = [("qkv", Linear), ("attn_out", Linear), ("attn_ln_w", vp), ("attn_ln_b", vp),
+                ("has_cross", i32), ("cross_index", i32),
+                ("cq", Linear), ("cross_out", Linear), ("cross_ln_w", vp), ("cross_ln_b", vp),
+                ("ffn_t_in", Linear), ("ffn_t_out", Linear), ("ffn_t_ln_w", vp), ("ffn_t_ln_b", vp),
+                ("ffn_q_in", Linear), ("ffn_q_out", Linear), ("ffn_q_ln_w", vp), ("ffn_q_ln_b", vp)]
+
+
+class QformerModel(C.Structure):
+    _fields_ = [("dtype", i32), ("hidden", i32), ("n_layers", i32), ("heads", i32), ("head_dim", i32), ("ffn", i32),
+                ("num_query", i32), ("enc_width", i32), ("embed_dim", i32), ("max_txt", i32), ("n_cross", i32),
+                ("ln_eps", f32), ("word_emb", vp), ("pos_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
+                ("query_tokens", vp), ("ckv_all", Linear), ("vision_proj", Linear), ("text_proj", Linear),
+                ("layers", C.POINTER(QfLayer))]
+
+
+# name -> (restype, argtypes); must list every symbol include/sprc.h declares
+SIGNATURES = {
+    "sprc_version": (i32, []),
+    "sprc_last_error": (C.c_char_p, []),
+    "sprc_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
+    "sprc_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "sprc_layernorm": (i32, [C.POINTER(LayerNormArgs), vp]),
+    "sprc_attention": (i32, [C.POINTER(AttentionArgs), vp]),
+    "sprc_im2row": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "sprc_vit_assemble": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sprc_qformer_embed": (i32, [C.POINTER(QformerEmbedArgs), vp]),
+    "sprc_l2norm_rows": (i32, [vp, i64, vp, vp, i64, i32, i32, i32, vp]),
+    "sprc_qformer_mask": (i32, [vp, vp, i32, i32, i32, vp]),
+    "sprc_sim_max": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "sprc_topk": (i32, [vp, i64, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "sprc_rank_of": (i32, [vp, i64, vp, i32, i32, i32, vp, vp]),
+    "sprc_vit_workspace_bytes": (sz, [C.POINTER(VitModel), i32]),
+    "sprc_qformer_workspace_bytes": (sz, [C.POINTER(QformerModel), i32]),
+    "sprc_vit_forward": (i32, [C.POINTER(VitModel), vp, i32, vp, vp, sz, vp]),
+    "sprc_qformer_image": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, vp, sz, vp]),
+    "sprc_qformer_fuse": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, i32, vp, vp, vp, sz, vp]),
+}
+
+_lib = None
+
+
+class SprcError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen libsprc_hip.so and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise SprcError(f"{LIB_PATH} is missing: the HIP extension is the only compute path "
+                        f"(build it with `python -m sprc_amd.build`)")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().sprc_last_error().decode(errors="replace")
+        raise SprcError(f"{what or 'sprc call'} failed (rc={rc}): {msg}")

@@ -1,0 +1,54 @@
+"""Build libsprc_hip.so (gfx950) in-tree with hipcc.  `python -m sprc_amd.build [--force]`."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent / "csrc"
+LIB = Path(__file__).resolve().parent / "libsprc_hip.so"
+SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "rank.hip", "models.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (Path(c).exists() or c == "hipcc"):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(out: Path, deps) -> bool:
+    return (not out.exists()) or any(Path(d).stat().st_mtime > out.stat().st_mtime for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    hipcc = _hipcc()
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+    headers = [CSRC / "common.hpp", CSRC.parent.parent / "include" / "sprc.h"]
+
+    def compile_one(src: str):
+        obj = objdir / (src + ".o")
+        if force or _stale(obj, [CSRC / src, *headers]):
+            cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,288 @@
+// attention.hip -- out = softmax(scale * Q K^T + key_mask) V  per (batch, head), no S x S matrix in HBM.
+//
+// bf16 kernel (MFMA, flash-style), one workgroup per (batch, head):
+//   * K  [Tk_pad][DHP] and V^T [DHP][Tk_pad] of the head are staged ONCE in LDS (Tk <= 257 on this
+//     path: 55 KiB + 55 KiB for ViT-g), padded row strides (DHP*2+16 B, Tk_pad*2+8 B) make the
+//     ds_read_b128 / ds_read_b64 fragment reads bank-conflict free.
+//   * every wave owns 32-row query tiles.  Per 32-key tile it computes the TRANSPOSED scores
+//     S^T = K . Q^T with v_mfma_f32_32x32x16_bf16, so a lane holds 16 keys of ONE query column:
+//     row max/sum are in-register plus one cross-half shuffle (guide: "swapped QK^T").
+//   * O^T = V^T . P^T keeps that query-per-lane layout, so the online-softmax rescale is a per-lane
+//     scalar and P never leaves registers: the MFMA k-index is an arbitrary permutation of the
+//     keys as long as P and V use the same one, which removes the permlane/LDS round trip.
+//   * head_dim 88 (EVA ViT-g) is zero-padded to 96 = 6 MFMA k-steps; Tk is padded to a multiple of
+//     32 with -inf scores.
+// f32 kernel: exact-fp32 VALU restatement for parity mode (one wave per query row).
+#include "common.hpp"
+
+namespace sprc {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnParams {
+    int B, H, Tq, Tk, dh;
+    const char* q; int64_t ldq;     // leading dims in ELEMENTS
+    const char* k; int64_t ldk;
+    const char* v; int64_t ldv;
+    char* out; int64_t ldo;
+    const float* key_mask;
+    float scale;
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int DHP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = DHP / 16;              // MFMA k-steps of QK^T
+    constexpr int DT = DHP / 32;              // 32-wide tiles of the head dim in O^T
+    constexpr int KROW = DHP * 2 + 16;        // bytes per K row in LDS
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    const int Tkp = (p.Tk + 31) & ~31;
+    const int VROW = Tkp * 2 + 8;             // bytes per V^T row in LDS
+    char* sK = smem;
+    char* sV = sK + (size_t)Tkp * KROW;
+    float* sM = reinterpret_cast<float*>(sV + (size_t)DHP * VROW);
+
+    const int dh = p.dh;
+    const char* kbase = p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2;
+    const char* vbase = p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2;
+
+    // ---- stage K (row-major, zero padded) ----
+    for (int it = tid; it < Tkp * (DHP / 8); it += 64 * NW) {
+        const int t = it / (DHP / 8), c = it % (DHP / 8);
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (t < p.Tk && c * 8 < dh) val = *reinterpret_cast<const u32x4*>(kbase + (int64_t)t * p.ldk * 2 + c * 16);
+        *reinterpret_cast<u32x4*>(sK + t * KROW + c * 16) = val;
+    }
+    // ---- stage V transposed: VT[d][key], two keys per 32-bit write ----
+    for (int it = tid; it < (Tkp / 2) * (DHP / 8); it += 64 * NW) {
+        const int kp = it % (Tkp / 2), c = it / (Tkp / 2);
+        const int t0 = kp * 2, t1 = t0 + 1;
+        u32x4 a = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
+        if (c * 8 < dh) {
+            if (t0 < p.Tk) a = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t0 * p.ldv * 2 + c * 16);
+            if (t1 < p.Tk) bb = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t1 * p.ldv * 2 + c * 16);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+            const uint32_t hi = (bb[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+            *reinterpret_cast<uint32_t*>(sV + (c * 8 + e) * VROW + t0 * 2) = lo | (hi << 16);
+        }
+    }
+    // ---- additive mask in the log2 domain; -inf on padded keys ----
+    for (int t = tid; t < Tkp; t += 64 * NW) {
+        float m = -INFINITY;
+        if (t < p.Tk) m = p.key_mask ? p.key_mask[(int64_t)b * p.Tk + t] * LOG2E : 0.f;
+        sM[t] = m;
+    }
+    __syncthreads();
+
+    const float sc = p.scale * LOG2E;
+    const int nqt = (p.Tq + 31) >> 5, nkt = Tkp >> 5;
+    for (int qt = wave; qt < nqt; qt += NW) {
+        // Q^T fragment (B operand): lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8]
+        const int qrow = min(qt * 32 + r32, p.Tq - 1);
+        const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + half * 8;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (d0 < dh) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
+            qf[ks] = __builtin_bit_cast(bf16x8, val);
+        }
+        f32x16 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+        for (int kt = 0; kt < nkt; ++kt) {
+            // S^T tile: rows = keys, col = query
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const char* krow = sK + (kt * 32 + r32) * KROW + half * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 32);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // scale + mask; key of reg r: kt*32 + (r&3) + 8*(r>>2) + 4*half
+            float mx = -INFINITY;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 mk = *reinterpret_cast<const f32x4*>(sM + kt * 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float val = s[g * 4 + e] * sc + mk[e];
+                    s[g * 4 + e] = val;
+                    mx = fmaxf(mx, val);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(s[r] - m_new);
+                s[r] = pv;
+                psum += pv;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            // P^T fragments (B operand): k-slot j uses this lane's regs 8j..8j+7
+            bf16x8 pf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u32x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
+                pf[j] = __builtin_bit_cast(bf16x8, pk);
+            }
+            // O^T += V^T . P^T ; A operand lane (d = r32, half): keys {16j+4half+0..3, 16j+8+4half+0..3}
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* vrow = sV + (dt * 32 + r32) * VROW + (kt * 32 + 4 * half) * 2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (16 * j) * 2);
+                    const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (16 * j + 8) * 2);
+                    const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j], o[dt], 0, 0, 0);
+                }
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qo = qt * 32 + r32;
+        if (qo < p.Tq) {
+            char* optr = p.out + (((int64_t)b * p.Tq + qo) * p.ldo + (int64_t)h * dh) * 2;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = dt * 32 + 8 * g + 4 * half;
+                    if (d0 < dh) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+                        pk.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+                        *reinterpret_cast<uint2*>(optr + d0 * 2) = pk;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// exact fp32: one wave per query row; lanes = keys for QK^T, lanes = head dims for PV.
+constexpr int F32_MAXK = 8;     // keys per lane -> Tk <= 512
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi_raw = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+    const bool valid = qi_raw < p.Tq;
+    const int qi = valid ? qi_raw : p.Tq - 1;
+    const int dh = p.dh;
+    float* qs = reinterpret_cast<float*>(smem) + wave * (dh + p.Tk);
+    float* ps = qs + dh;
+    const float* q = reinterpret_cast<const float*>(p.q) + ((int64_t)b * p.Tq + qi) * p.ldq + (int64_t)h * dh;
+    const float* kb = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.Tk * p.ldk + (int64_t)h * dh;
+    const float* vb = reinterpret_cast<const float*>(p.v) + (int64_t)b * p.Tk * p.ldv + (int64_t)h * dh;
+    for (int d = lane; d < dh; d += 64) qs[d] = q[d];
+    __syncthreads();
+    float s[F32_MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < F32_MAXK; ++i) {
+        const int key = lane + i * 64;
+        s[i] = -INFINITY;
+        if (key < p.Tk) {
+            const float* kr = kb + (int64_t)key * p.ldk;
+            float acc = 0.f;
+            for (int d = 0; d < dh; d += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(kr + d);
+                acc = fmaf(qs[d], kv.x, acc); acc = fmaf(qs[d + 1], kv.y, acc);
+                acc = fmaf(qs[d + 2], kv.z, acc); acc = fmaf(qs[d + 3], kv.w, acc);
+            }
+            s[i] = acc * p.scale + (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + key] : 0.f);
+            mx = fmaxf(mx, s[i]);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < F32_MAXK; ++i) {
+        const int key = lane + i * 64;
+        if (key < p.Tk) {
+            const float e = expf(s[i] - mx);
+            ps[key] = e;
+            sum += e;
+        }
+    }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    float* o = reinterpret_cast<float*>(p.out) + ((int64_t)b * p.Tq + qi) * p.ldo + (int64_t)h * dh;
+    for (int d = lane; d < dh; d += 64) {
+        float acc = 0.f;
+        for (int key = 0; key < p.Tk; ++key) acc = fmaf(ps[key], vb[(int64_t)key * p.ldv + d], acc);
+        if (valid) o[d] = acc * inv;
+    }
+}
+
+template <int DHP, int NW>
+static int launch_bf16(const AttnParams& p, hipStream_t st) {
+    const int Tkp = (p.Tk + 31) & ~31;
+    const size_t lds = (size_t)Tkp * (DHP * 2 + 16) + (size_t)DHP * (Tkp * 2 + 8) + (size_t)Tkp * 4;
+    if (lds > 160 * 1024) {
+        set_error("sprc_attention: Tk=%d needs %zu bytes of LDS (max 163840)", p.Tk, lds);
+        return SPRC_EUNSUPPORTED;
+    }
+    auto kern = attn_bf16_kernel<DHP, NW>;
+    static size_t attr = 0;
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * NW), lds, st, p);
+    SPRC_CHECK_LAUNCH("sprc_attention(bf16)");
+    return SPRC_OK;
+}
+
+}  // namespace sprc
+
+extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
+    using namespace sprc;
+    SPRC_REQUIRE(a && a->q && a->k && a->v && a->out, "sprc_attention: null pointer");
+    SPRC_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0 && a->head_dim > 0, "sprc_attention: bad shape");
+    AttnParams p{a->B, a->H, a->Tq, a->Tk, a->head_dim, (const char*)a->q, a->ldq, (const char*)a->k, a->ldk,
+                 (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale};
+    hipStream_t st = (hipStream_t)s;
+    if (a->dtype == SPRC_BF16) {
+        SPRC_REQUIRE(a->head_dim % 8 == 0 && a->head_dim <= 96, "sprc_attention(bf16): head_dim=%d unsupported", a->head_dim);
+        SPRC_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0,
+                     "sprc_attention(bf16): leading dims must be multiples of 8");
+        SPRC_REQUIRE(((uintptr_t)a->q % 16) == 0 && ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0 &&
+                         ((uintptr_t)a->out % 8) == 0, "sprc_attention(bf16): misaligned pointer");
+        const bool small = a->Tq <= 128;
+        if (a->head_dim <= 64) return small ? launch_bf16<64, 4>(p, st) : launch_bf16<64, 8>(p, st);
+        return small ? launch_bf16<96, 4>(p, st) : launch_bf16<96, 8>(p, st);
+    }
+    SPRC_REQUIRE(a->dtype == SPRC_F32, "sprc_attention: bad dtype %d", a->dtype);
+    SPRC_REQUIRE(a->Tk <= 64 * F32_MAXK, "sprc_attention(f32): Tk=%d > %d", a->Tk, 64 * F32_MAXK);
+    SPRC_REQUIRE(a->head_dim % 4 == 0 && a->ldk % 4 == 0, "sprc_attention(f32): head_dim/ldk must be multiples of 4");
+    const size_t lds = 4 * (size_t)(a->head_dim + a->Tk) * sizeof(float);
+    hipLaunchKernelGGL(attn_f32_kernel, dim3((a->Tq + 3) / 4, a->H, a->B), dim3(256), lds, st, p);
+    SPRC_CHECK_LAUNCH("sprc_attention(f32)");
+    return SPRC_OK;
+}

@@ -1,0 +1,71 @@
+// common.hpp -- shared device/host helpers for the gfx950 kernels of libsprc_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sprc.h"
+
+namespace sprc {
+
+// ---- error plumbing --------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define SPRC_REQUIRE(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            ::sprc::set_error(__VA_ARGS__);             \
+            return SPRC_EINVAL;                         \
+        }                                               \
+    } while (0)
+#define SPRC_CHECK_LAUNCH(name)                                                     \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            ::sprc::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return SPRC_ELAUNCH;                                                    \
+        }                                                                           \
+    } while (0)
+
+// ---- types -----------------------------------------------------------------------------------
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {   // round-to-nearest-even, NaN-preserving
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__host__ __device__ __forceinline__ int64_t map_row(const sprc_rowmap& m, int64_t r) {
+    if (m.rows_per_group <= 0) return r;
+    return (r / m.rows_per_group) * (int64_t)m.group_stride + (r % m.rows_per_group) + m.group_offset;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+
+static inline size_t dtype_size(int dt) { return dt == SPRC_BF16 ? 2 : 4; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace sprc

@@ -1,0 +1,296 @@
+// models.hip -- composite forward passes: the kernels of gemm/attention/rowops sequenced on one
+// stream, one C call per batch.  Activations live in a caller-provided workspace (bump allocated);
+// the residual stream, LayerNorm statistics and softmax stay fp32, GEMM operands are `dtype`.
+//
+//   sprc_vit_forward    eva_vit.py:324-340 / clip_vit.py:171-185 + ln_vision (blip2.py:193-199)
+//   sprc_qformer_image  Qformer.py:810-973 call shape (i)  + vision_proj + normalize (align_prompt.py:369-385)
+//   sprc_qformer_fuse   call shapes (ii)+(iii) + text_proj + normalize (align_prompt.py:313-350)
+#include "common.hpp"
+
+namespace sprc {
+
+struct Bump {
+    char* base; size_t cap, off; bool ok;
+    Bump(void* p, size_t c) : base((char*)p), cap(c), off(0), ok(true) {}
+    void* take(size_t bytes) {
+        const size_t o = align_up(off, 256);
+        if (base == nullptr) { off = o + bytes; return nullptr; }     // sizing pass
+        if (o + bytes > cap) { ok = false; return base; }
+        off = o + bytes;
+        return base + o;
+    }
+};
+
+static const sprc_rowmap ID_MAP = {0, 0, 0};
+
+static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
+                void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0,
+                sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP) {
+    sprc_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
+    g.A = A; g.lda = lda; g.amap = amap;
+    g.W = w.w; g.ldw = K; g.bias = w.b;
+    g.resid = resid; g.ldr = ldr;
+    g.C = C; g.ldc = ldc; g.cmap = cmap;
+    return sprc_gemm(&g, st);
+}
+
+static int lnorm(hipStream_t st, int dt, int M, int D, const float* x, const float* gam, const float* bet, float eps,
+                 float* y32, void* y16, sprc_rowmap map = ID_MAP) {
+    sprc_layernorm_args a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.D = D; a.out_dtype = dt;
+    a.x = x; a.ldx = D; a.xmap = map;
+    a.gamma = gam; a.beta = bet; a.eps = eps;
+    a.y32 = y32; a.ld32 = D; a.ymap = map;
+    a.y16 = y16; a.ld16 = D;
+    return sprc_layernorm(&a, st);
+}
+
+static int attn(hipStream_t st, int dt, int B, int H, int Tq, int Tk, int dh, const void* q, int64_t ldq, const void* k,
+                int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, const float* mask, float scale) {
+    sprc_attention_args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.head_dim = dh; a.dtype = dt;
+    a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
+    a.key_mask = mask; a.scale = scale;
+    return sprc_attention(&a, st);
+}
+
+#define RUN(x)                      \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != SPRC_OK) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+struct VitBufs { void *rows, *h, *qkv, *ctx, *mlp; float *pout, *x; };
+
+static size_t vit_plan(const sprc_vit_model* m, int B, Bump& b, VitBufs& v) {
+    const size_t es = dtype_size(m->dtype);
+    const size_t M = (size_t)B * m->tokens, P = (size_t)B * (m->tokens - 1), D = m->width;
+    v.rows = b.take(P * m->patch_k_pad * es);
+    v.pout = (float*)b.take(P * D * 4);
+    v.x = (float*)b.take(M * D * 4);
+    v.h = b.take(M * D * es);
+    v.qkv = b.take(M * 3 * D * es);
+    v.ctx = b.take(M * D * es);
+    v.mlp = b.take(M * (size_t)m->mlp * es);
+    return b.off;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct QfBufs {
+    void *enc, *kv, *h16, *a16, *g16, *qkv, *ctx, *cq, *ffn;
+    float *h32, *a32, *g32, *t32, *proj, *mask;
+};
+
+static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& b, QfBufs& q) {
+    const size_t es = dtype_size(m->dtype);
+    const size_t S = (size_t)m->num_query + m->max_txt, R = (size_t)B * S, Hd = m->hidden;
+    const size_t E = (size_t)B * enc_tokens;
+    q.enc = (m->dtype == SPRC_BF16) ? b.take(E * m->enc_width * es) : nullptr;
+    q.kv = b.take(E * (size_t)m->n_cross * 2 * Hd * es);
+    q.h32 = (float*)b.take(R * Hd * 4); q.h16 = b.take(R * Hd * es);
+    q.a32 = (float*)b.take(R * Hd * 4); q.a16 = b.take(R * Hd * es);
+    q.g32 = (float*)b.take(R * Hd * 4); q.g16 = b.take(R * Hd * es);
+    q.t32 = (float*)b.take(R * Hd * 4);
+    q.qkv = b.take(R * 3 * Hd * es);
+    q.ctx = b.take(R * Hd * es);
+    q.cq = b.take(R * Hd * es);
+    q.ffn = b.take(R * (size_t)m->ffn * es);
+    q.proj = (float*)b.take(R * (size_t)m->embed_dim * 4);
+    q.mask = (float*)b.take(R * 4);
+    return b.off;
+}
+
+// one Q-Former encoder stack over x32/x16 [B, S, hidden]; cross-attention + query FFN on rows [:Lq] when
+// `kv` is given (Qformer.py:434-468), text FFN on rows [Lq:]; text FFN on all rows otherwise (:469-475).
+static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int B, int S, int enc_tokens, bool with_enc,
+                    const float* mask, float* x32, void* x16) {
+    const int dt = m->dtype, Hd = m->hidden, H = m->heads, dh = m->head_dim, F = m->ffn, Lq = m->num_query;
+    const int R = B * S;
+    const float sc = 1.0f / sqrtf((float)dh);                                   // Qformer.py:250
+    const size_t es = dtype_size(dt);
+    const int64_t ldkv = (int64_t)m->n_cross * 2 * Hd;
+    const sprc_rowmap qmap = {Lq, S, 0}, tmap = {S - Lq, S, Lq};
+    const bool split = with_enc && S > Lq;         // rows [:Lq] and [Lq:] take different paths
+    for (int l = 0; l < m->n_layers; ++l) {
+        const sprc_qf_layer& L = m->layers[l];
+        // self-attention over all S rows
+        RUN(gemm(st, dt, dt, R, 3 * Hd, Hd, x16, Hd, L.qkv, q.qkv, 3 * Hd));
+        RUN(attn(st, dt, B, H, S, S, dh, q.qkv, 3 * Hd, (char*)q.qkv + Hd * es, 3 * Hd, (char*)q.qkv + 2 * Hd * es, 3 * Hd,
+                 q.ctx, Hd, mask, sc));
+        RUN(gemm(st, dt, SPRC_F32, R, Hd, Hd, q.ctx, Hd, L.attn_out, q.t32, Hd, SPRC_ACT_NONE, x32, Hd));
+        RUN(lnorm(st, dt, R, Hd, q.t32, L.attn_ln_w, L.attn_ln_b, m->ln_eps, q.a32, q.a16));
+        if (with_enc) {
+            const sprc_rowmap rq = split ? qmap : ID_MAP;
+            const int Rq = B * Lq;
+            if (L.has_cross) {
+                RUN(gemm(st, dt, dt, Rq, Hd, Hd, q.a16, Hd, L.cq, q.cq, Hd, SPRC_ACT_NONE, nullptr, 0, rq));
+                const char* kp = (const char*)q.kv + (size_t)L.cross_index * 2 * Hd * es;
+                RUN(attn(st, dt, B, H, Lq, enc_tokens, dh, q.cq, Hd, kp, ldkv, kp + Hd * es, ldkv, q.ctx, Hd, nullptr, sc));
+                RUN(gemm(st, dt, SPRC_F32, Rq, Hd, Hd, q.ctx, Hd, L.cross_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, rq));
+                RUN(lnorm(st, dt, Rq, Hd, q.t32, L.cross_ln_w, L.cross_ln_b, m->ln_eps, q.a32, q.a16, rq));
+            }
+            RUN(gemm(st, dt, dt, Rq, F, Hd, q.a16, Hd, L.ffn_q_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, rq));
+            RUN(gemm(st, dt, SPRC_F32, Rq, Hd, F, q.ffn, F, L.ffn_q_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, rq));
+            RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, rq));
+            if (split) {
+                const int Rt = B * (S - Lq);
+                RUN(gemm(st, dt, dt, Rt, F, Hd, q.a16, Hd, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, tmap));
+                RUN(gemm(st, dt, SPRC_F32, Rt, Hd, F, q.ffn, F, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, tmap));
+                RUN(lnorm(st, dt, Rt, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
+            }
+        } else {
+            RUN(gemm(st, dt, dt, R, F, Hd, q.a16, Hd, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU));
+            RUN(gemm(st, dt, SPRC_F32, R, Hd, F, q.ffn, F, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd));
+            RUN(lnorm(st, dt, R, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16));
+        }
+    }
+    return SPRC_OK;
+}
+
+// K|V projections of the image tokens for every cross-attention layer in ONE GEMM (Qformer.py:191-193)
+static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, const float* enc32, int B, int enc_tokens) {
+    const int E = B * enc_tokens;
+    const void* enc = enc32;
+    if (m->dtype == SPRC_BF16) {
+        RUN(sprc_cast_f32_to_bf16(enc32, (uint16_t*)q.enc, (size_t)E * m->enc_width, st));
+        enc = q.enc;
+    }
+    const int Nkv = m->n_cross * 2 * m->hidden;
+    return gemm(st, m->dtype, m->dtype, E, Nkv, m->enc_width, enc, m->enc_width, m->ckv_all, q.kv, Nkv);
+}
+
+static int check_qf(const sprc_qformer_model* m) {
+    SPRC_REQUIRE(m && m->layers, "qformer: null model");
+    SPRC_REQUIRE(m->dtype == SPRC_BF16 || m->dtype == SPRC_F32, "qformer: bad dtype");
+    SPRC_REQUIRE(m->hidden == m->heads * m->head_dim, "qformer: hidden != heads*head_dim");
+    SPRC_REQUIRE((m->num_query & (m->num_query - 1)) == 0 && (m->max_txt & (m->max_txt - 1)) == 0,
+                 "qformer: num_query and max_txt must be powers of two");
+    return SPRC_OK;
+}
+
+}  // namespace sprc
+
+using namespace sprc;
+
+extern "C" size_t sprc_vit_workspace_bytes(const sprc_vit_model* m, int32_t B) {
+    if (!m || B <= 0) return 0;
+    Bump b(nullptr, 0);
+    VitBufs v;
+    return vit_plan(m, B, b, v) + 256;
+}
+
+extern "C" size_t sprc_qformer_workspace_bytes(const sprc_qformer_model* m, int32_t B) {
+    if (!m || B <= 0) return 0;
+    Bump b(nullptr, 0);
+    QfBufs q;
+    return qf_plan(m, B, 257, b, q) + 256;
+}
+
+extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, int32_t B, float* raw, void* ws,
+                                size_t ws_bytes, sprc_stream s) {
+    SPRC_REQUIRE(m && m->layers && images && raw && ws, "sprc_vit_forward: null pointer");
+    SPRC_REQUIRE(B > 0, "sprc_vit_forward: B=%d", B);
+    SPRC_REQUIRE(m->dtype == SPRC_BF16 || m->dtype == SPRC_F32, "sprc_vit_forward: bad dtype");
+    SPRC_REQUIRE(m->width == m->heads * m->head_dim, "sprc_vit_forward: width != heads*head_dim");
+    SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_vit_forward: workspace must be 256-byte aligned");
+    Bump b(ws, ws_bytes);
+    VitBufs v;
+    vit_plan(m, B, b, v);
+    if (!b.ok) {
+        set_error("sprc_vit_forward: workspace too small (%zu bytes given)", ws_bytes);
+        return SPRC_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int dt = m->dtype, D = m->width, T = m->tokens, M = B * T, P = B * (T - 1), F = m->mlp;
+    const size_t es = dtype_size(dt);
+    const float scale = 1.0f / sqrtf((float)m->head_dim);                       // eva_vit.py:74
+    RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, dt, st));
+    RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D));
+    RUN(sprc_vit_assemble(v.pout, m->cls, m->pos, v.x, B, T, D, st));
+    if (m->has_ln_pre) RUN(lnorm(st, dt, M, D, v.x, m->ln_pre_w, m->ln_pre_b, m->ln_eps, v.x, nullptr));
+    for (int l = 0; l < m->depth; ++l) {
+        const sprc_vit_layer& L = m->layers[l];
+        RUN(lnorm(st, dt, M, D, v.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, v.h));
+        RUN(gemm(st, dt, dt, M, 3 * D, D, v.h, D, L.qkv, v.qkv, 3 * D));
+        RUN(attn(st, dt, B, m->heads, T, T, m->head_dim, v.qkv, 3 * D, (char*)v.qkv + D * es, 3 * D,
+                 (char*)v.qkv + 2 * D * es, 3 * D, v.ctx, D, nullptr, scale));
+        RUN(gemm(st, dt, SPRC_F32, M, D, D, v.ctx, D, L.proj, v.x, D, SPRC_ACT_NONE, v.x, D));
+        RUN(lnorm(st, dt, M, D, v.x, L.ln2_w, L.ln2_b, m->ln_eps, nullptr, v.h));
+        RUN(gemm(st, dt, dt, M, F, D, v.h, D, L.fc1, v.mlp, F, m->act));
+        RUN(gemm(st, dt, SPRC_F32, M, D, F, v.mlp, F, L.fc2, v.x, D, SPRC_ACT_NONE, v.x, D));
+    }
+    RUN(lnorm(st, dt, M, D, v.x, m->ln_vision_w, m->ln_vision_b, m->ln_vision_eps, raw, nullptr));
+    return SPRC_OK;
+}
+
+extern "C" int sprc_qformer_image(const sprc_qformer_model* m, const float* raw, int32_t B, float* feats, void* feats16,
+                                  void* ws, size_t ws_bytes, sprc_stream s) {
+    RUN(check_qf(m));
+    SPRC_REQUIRE(raw && feats && ws && B > 0, "sprc_qformer_image: bad arguments");
+    SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_qformer_image: workspace must be 256-byte aligned");
+    const int T = 257;
+    Bump b(ws, ws_bytes);
+    QfBufs q;
+    qf_plan(m, B, T, b, q);
+    if (!b.ok) {
+        set_error("sprc_qformer_image: workspace too small (%zu bytes given)", ws_bytes);
+        return SPRC_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query;
+    RUN(qf_encode_kv(m, st, q, raw, B, T));
+    sprc_qformer_embed_args e;
+    memset(&e, 0, sizeof(e));
+    e.B = B; e.Lq = Lq; e.Lt = 0; e.hidden = Hd; e.out_dtype = dt;
+    e.query_embeds = m->query_tokens; e.q_bstride = 0;
+    e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
+    e.y32 = q.h32; e.y16 = q.h16;
+    RUN(sprc_qformer_embed(&e, st));
+    RUN(qf_stack(m, st, q, B, Lq, T, true, nullptr, q.h32, q.h16));
+    RUN(gemm(st, dt, SPRC_F32, B * Lq, m->embed_dim, Hd, q.h16, Hd, m->vision_proj, q.proj, m->embed_dim));
+    return sprc_l2norm_rows(q.proj, m->embed_dim, feats, feats16, m->embed_dim, B * Lq, m->embed_dim, dt, st);
+}
+
+extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
+                                 const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
+                                 void* fusion16, void* ws, size_t ws_bytes, sprc_stream s) {
+    RUN(check_qf(m));
+    SPRC_REQUIRE(ref_embeds && input_ids && attention_mask && fusion && ws && B > 0, "sprc_qformer_fuse: bad arguments");
+    SPRC_REQUIRE(enc_tokens == 257, "sprc_qformer_fuse: enc_tokens=%d (workspace is planned for 257)", enc_tokens);
+    SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_qformer_fuse: workspace must be 256-byte aligned");
+    Bump b(ws, ws_bytes);
+    QfBufs q;
+    qf_plan(m, B, enc_tokens, b, q);
+    if (!b.ok) {
+        set_error("sprc_qformer_fuse: workspace too small (%zu bytes given)", ws_bytes);
+        return SPRC_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query, Lt = m->max_txt, S = Lq + Lt;
+    RUN(qf_encode_kv(m, st, q, ref_embeds, B, enc_tokens));
+    RUN(sprc_qformer_mask(attention_mask, q.mask, B, Lq, Lt, st));
+    sprc_qformer_embed_args e;
+    memset(&e, 0, sizeof(e));
+    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt;
+    e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
+    e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
+    // pass 1: learned query tokens + text, cross-attention to the reference image (align_prompt.py:332-339)
+    e.query_embeds = m->query_tokens; e.q_bstride = 0;
+    e.y32 = q.h32; e.y16 = q.h16;
+    RUN(sprc_qformer_embed(&e, st));
+    RUN(qf_stack(m, st, q, B, S, enc_tokens, true, q.mask, q.h32, q.h16));
+    // pass 2: pass-1 query rows as query_embeds (re-LayerNormed by the embedding LN), no image (:341-346)
+    e.query_embeds = q.h32; e.q_bstride = (int64_t)S * Hd;
+    e.y32 = q.g32; e.y16 = q.g16;
+    RUN(sprc_qformer_embed(&e, st));
+    RUN(qf_stack(m, st, q, B, S, enc_tokens, false, q.mask, q.g32, q.g16));
+    // fusion = normalize(text_proj(pass2[:, 32, :]))  (:348-350): row Lq of every sample
+    const sprc_rowmap cls_row = {1, S, Lq};
+    RUN(gemm(st, dt, SPRC_F32, B, m->embed_dim, Hd, q.g16, Hd, m->text_proj, q.proj, m->embed_dim, SPRC_ACT_NONE, nullptr, 0, cls_row));
+    return sprc_l2norm_rows(q.proj, m->embed_dim, fusion, fusion16, m->embed_dim, B, m->embed_dim, dt, st);
+}

@@ -1,0 +1,285 @@
+// rowops.hip -- HBM-bound row kernels: LayerNorm, L2-normalise, embeddings, patch extraction, casts.
+//
+// One 64-lane wave owns one row; the row lives in registers as up to MAXC float4 chunks per lane
+// (D <= 2048, D % 4 == 0; the path uses 1408 / 1024 / 768 / 256), loads/stores are 16 B per lane and
+// coalesced, statistics are fp32 two-pass (mean, then centred variance) reduced with wave shuffles.
+#include "common.hpp"
+
+namespace sprc {
+
+constexpr int MAXC = 8;          // float4 chunks per lane -> D <= 64*4*8 = 2048
+constexpr int ROWS_PER_BLOCK = 4;
+
+struct RowRegs {
+    float4 v[MAXC];
+};
+
+__device__ __forceinline__ void load_row(RowRegs& r, const float* x, int nch, int lane) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        r.v[c] = (i < nch) ? reinterpret_cast<const float4*>(x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+__device__ __forceinline__ void layernorm_regs(RowRegs& r, int nch, int D, int lane, const float* gamma,
+                                               const float* beta, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) s += (r.v[c].x + r.v[c].y) + (r.v[c].z + r.v[c].w);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        if (lane + c * 64 < nch) {
+            const float a = r.v[c].x - mean, b = r.v[c].y - mean, cc = r.v[c].z - mean, d = r.v[c].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nch) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+            const float4 b = reinterpret_cast<const float4*>(beta)[i];
+            r.v[c].x = (r.v[c].x - mean) * rstd * g.x + b.x;
+            r.v[c].y = (r.v[c].y - mean) * rstd * g.y + b.y;
+            r.v[c].z = (r.v[c].z - mean) * rstd * g.z + b.z;
+            r.v[c].w = (r.v[c].w - mean) * rstd * g.w + b.w;
+        }
+    }
+}
+
+template <bool OUT16_IS_BF16>
+__device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y16, int nch, int lane) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nch) {
+            if (y32) reinterpret_cast<float4*>(y32)[i] = r.v[c];
+            if (y16) {
+                if constexpr (OUT16_IS_BF16) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(r.v[c].x, r.v[c].y);
+                    pk.y = pack_bf16x2(r.v[c].z, r.v[c].w);
+                    reinterpret_cast<uint2*>(y16)[i] = pk;
+                } else {
+                    reinterpret_cast<float4*>(y16)[i] = r.v[c];
+                }
+            }
+        }
+    }
+}
+
+struct LnParams {
+    int M, D;
+    const float* x; int64_t ldx; sprc_rowmap xmap;
+    const float* gamma; const float* beta; float eps;
+    float* y32; int64_t ld32; sprc_rowmap ymap;
+    void* y16; int64_t ld16;
+};
+
+template <bool BF16>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nch = p.D >> 2;
+    RowRegs r;
+    load_row(r, p.x + map_row(p.xmap, row) * p.ldx, nch, lane);
+    layernorm_regs(r, nch, p.D, lane, p.gamma, p.beta, p.eps);
+    const int64_t yr = map_row(p.ymap, row);
+    store_row<BF16>(r, p.y32 ? p.y32 + yr * p.ld32 : nullptr,
+                    p.y16 ? (char*)p.y16 + yr * p.ld16 * (BF16 ? 2 : 4) : nullptr, nch, lane);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc_qformer_embed_args p) {
+    const int lane = threadIdx.x & 63;
+    const int S = p.Lq + p.Lt;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= p.B * S) return;
+    const int b = row / S, t = row % S;
+    const int nch = p.hidden >> 2;
+    RowRegs r;
+    if (t < p.Lq) {
+        load_row(r, p.query_embeds + (int64_t)b * p.q_bstride + (int64_t)t * p.hidden, nch, lane);
+    } else {
+        const int pos = t - p.Lq;
+        const int64_t id = p.input_ids[(int64_t)b * p.Lt + pos];
+        RowRegs pe;
+        load_row(r, p.word_emb + id * p.hidden, nch, lane);
+        load_row(pe, p.pos_emb + (int64_t)pos * p.hidden, nch, lane);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            r.v[c].x += pe.v[c].x; r.v[c].y += pe.v[c].y; r.v[c].z += pe.v[c].z; r.v[c].w += pe.v[c].w;
+        }
+    }
+    layernorm_regs(r, nch, p.hidden, lane, p.gamma, p.beta, p.eps);
+    store_row<BF16>(r, p.y32 ? p.y32 + (int64_t)row * p.hidden : nullptr,
+                    p.y16 ? (char*)p.y16 + (int64_t)row * p.hidden * (BF16 ? 2 : 4) : nullptr, nch, lane);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void l2norm_kernel(const float* x, int64_t ldx, float* y32, void* y16,
+                                                                     int64_t ldy, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nch = D >> 2;
+    RowRegs r;
+    load_row(r, x + (int64_t)row * ldx, nch, lane);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) q += (r.v[c].x * r.v[c].x + r.v[c].y * r.v[c].y) + (r.v[c].z * r.v[c].z + r.v[c].w * r.v[c].w);
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);       // F.normalize: x / max(||x||, eps)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { r.v[c].x *= inv; r.v[c].y *= inv; r.v[c].z *= inv; r.v[c].w *= inv; }
+    store_row<BF16>(r, y32 ? y32 + (int64_t)row * ldy : nullptr,
+                    y16 ? (char*)y16 + (int64_t)row * ldy * (BF16 ? 2 : 4) : nullptr, nch, lane);
+}
+
+__global__ void cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        uint2 pk;
+        pk.x = pack_bf16x2(v.x, v.y);
+        pk.y = pack_bf16x2(v.z, v.w);
+        reinterpret_cast<uint2*>(dst)[i] = pk;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = f32_to_bf16_bits(src[i]);
+}
+
+// rows[(b*G*G + py*G + px), k] = image[b, c, py*P + i, px*P + j],  k = c*P*P + i*P + j  (zero for k >= 3*P*P)
+template <bool BF16>
+__global__ void im2row_kernel(const float* __restrict__ img, void* __restrict__ rows, int B, int S, int P, int kpad) {
+    const int G = S / P, PP = P * P, kreal = 3 * PP;
+    const int64_t total = (int64_t)B * G * G * kpad;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int k = (int)(e % kpad);
+        const int64_t row = e / kpad;
+        float v = 0.f;
+        if (k < kreal) {
+            const int c = k / PP, ij = k % PP, i = ij / P, j = ij % P;
+            const int px = (int)(row % G), py = (int)((row / G) % G);
+            const int64_t b = row / (G * G);
+            v = img[((b * 3 + c) * S + (py * P + i)) * (int64_t)S + (px * P + j)];
+        }
+        if constexpr (BF16) reinterpret_cast<uint16_t*>(rows)[e] = f32_to_bf16_bits(v);
+        else reinterpret_cast<float*>(rows)[e] = v;
+    }
+}
+
+__global__ void vit_assemble_kernel(const float* __restrict__ patch_out, const float* __restrict__ cls,
+                                    const float* __restrict__ pos, float* __restrict__ x, int B, int T, int W4) {
+    const int64_t total = (int64_t)B * T * W4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int c = (int)(e % W4);
+        const int t = (int)((e / W4) % T);
+        const int64_t b = e / ((int64_t)W4 * T);
+        const float4 pe = reinterpret_cast<const float4*>(pos)[(int64_t)t * W4 + c];
+        const float4 v = (t == 0) ? reinterpret_cast<const float4*>(cls)[c]
+                                  : reinterpret_cast<const float4*>(patch_out)[(b * (T - 1) + (t - 1)) * W4 + c];
+        reinterpret_cast<float4*>(x)[e] = make_float4(v.x + pe.x, v.y + pe.y, v.z + pe.z, v.w + pe.w);
+    }
+}
+
+__global__ void qformer_mask_kernel(const int64_t* __restrict__ mask, float* __restrict__ out, int B, int Lq, int Lt) {
+    const int S = Lq + Lt;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * S) return;
+    const int b = i / S, j = i % S;
+    out[i] = (j < Lq) ? 0.f : (1.0f - (float)mask[(int64_t)b * Lt + (j - Lq)]) * -10000.0f;
+}
+
+static int grid_for(int64_t n, int block, int cap = 256 * 8) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace sprc
+
+using namespace sprc;
+
+extern "C" int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s) {
+    SPRC_REQUIRE(src && dst, "sprc_cast_f32_to_bf16: null pointer");
+    if (n == 0) return SPRC_OK;
+    SPRC_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "sprc_cast_f32_to_bf16: misaligned");
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for((int64_t)(n / 4 + 1), 256)), dim3(256), 0, (hipStream_t)s, src, dst, n);
+    SPRC_CHECK_LAUNCH("sprc_cast_f32_to_bf16");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
+    SPRC_REQUIRE(a && a->x && a->gamma && a->beta, "sprc_layernorm: null pointer");
+    SPRC_REQUIRE(a->M > 0, "sprc_layernorm: M=%d", a->M);
+    SPRC_REQUIRE(a->D > 0 && a->D % 4 == 0 && a->D <= 64 * 4 * MAXC, "sprc_layernorm: D=%d unsupported (D%%4==0, D<=2048)", a->D);
+    SPRC_REQUIRE(a->ldx % 4 == 0 && (!a->y32 || a->ld32 % 4 == 0) && (!a->y16 || a->ld16 % 4 == 0),
+                 "sprc_layernorm: leading dimensions must be multiples of 4");
+    SPRC_REQUIRE(a->y32 || a->y16, "sprc_layernorm: no output");
+    LnParams p{a->M, a->D, a->x, a->ldx, a->xmap, a->gamma, a->beta, a->eps, a->y32, a->ld32, a->ymap, a->y16, a->ld16};
+    const dim3 grid((a->M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
+    if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, (hipStream_t)s, p);
+    SPRC_CHECK_LAUNCH("sprc_layernorm");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream s) {
+    SPRC_REQUIRE(a && a->query_embeds && a->gamma && a->beta, "sprc_qformer_embed: null pointer");
+    SPRC_REQUIRE(a->B > 0 && a->Lq > 0 && a->Lt >= 0, "sprc_qformer_embed: bad shape");
+    SPRC_REQUIRE(a->Lt == 0 || (a->input_ids && a->word_emb && a->pos_emb), "sprc_qformer_embed: text tables missing");
+    SPRC_REQUIRE(a->hidden % 4 == 0 && a->hidden <= 64 * 4 * MAXC, "sprc_qformer_embed: hidden=%d unsupported", a->hidden);
+    const int rows = a->B * (a->Lq + a->Lt);
+    const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
+    if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(qformer_embed_kernel<true>, grid, block, 0, (hipStream_t)s, *a);
+    else hipLaunchKernelGGL(qformer_embed_kernel<false>, grid, block, 0, (hipStream_t)s, *a);
+    SPRC_CHECK_LAUNCH("sprc_qformer_embed");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_l2norm_rows(const float* x, int64_t ldx, float* y32, void* y16, int64_t ldy, int32_t M, int32_t D,
+                                int32_t out_dtype, sprc_stream s) {
+    SPRC_REQUIRE(x && (y32 || y16), "sprc_l2norm_rows: null pointer");
+    SPRC_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC && ldx % 4 == 0 && ldy % 4 == 0, "sprc_l2norm_rows: bad shape");
+    const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
+    if (out_dtype == SPRC_BF16) hipLaunchKernelGGL(l2norm_kernel<true>, grid, block, 0, (hipStream_t)s, x, ldx, y32, y16, ldy, M, D);
+    else hipLaunchKernelGGL(l2norm_kernel<false>, grid, block, 0, (hipStream_t)s, x, ldx, y32, y16, ldy, M, D);
+    SPRC_CHECK_LAUNCH("sprc_l2norm_rows");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_im2row(const float* images, void* rows, int32_t B, int32_t image, int32_t patch, int32_t k_pad,
+                           int32_t dtype, sprc_stream s) {
+    SPRC_REQUIRE(images && rows, "sprc_im2row: null pointer");
+    SPRC_REQUIRE(B > 0 && patch > 0 && image % patch == 0 && k_pad >= 3 * patch * patch, "sprc_im2row: bad shape");
+    const int64_t total = (int64_t)B * (image / patch) * (image / patch) * k_pad;
+    if (dtype == SPRC_BF16) hipLaunchKernelGGL(im2row_kernel<true>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
+    else hipLaunchKernelGGL(im2row_kernel<false>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
+    SPRC_CHECK_LAUNCH("sprc_im2row");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_vit_assemble(const float* patch_out, const float* cls, const float* pos, float* x, int32_t B,
+                                 int32_t tokens, int32_t width, sprc_stream s) {
+    SPRC_REQUIRE(patch_out && cls && pos && x, "sprc_vit_assemble: null pointer");
+    SPRC_REQUIRE(B > 0 && tokens > 1 && width % 4 == 0, "sprc_vit_assemble: bad shape");
+    const int64_t total = (int64_t)B * tokens * (width / 4);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, patch_out, cls, pos, x, B, tokens, width / 4);
+    SPRC_CHECK_LAUNCH("sprc_vit_assemble");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_qformer_mask(const int64_t* attention_mask, float* out, int32_t B, int32_t Lq, int32_t Lt, sprc_stream s) {
+    SPRC_REQUIRE(attention_mask && out && B > 0 && Lq >= 0 && Lt > 0, "sprc_qformer_mask: bad arguments");
+    const int n = B * (Lq + Lt);
+    hipLaunchKernelGGL(qformer_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, attention_mask, out, B, Lq, Lt);
+    SPRC_CHECK_LAUNCH("sprc_qformer_mask");
+    return SPRC_OK;
+}

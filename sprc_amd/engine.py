@@ -1,0 +1,314 @@
+"""Host-side driver of libsprc_hip.so: packs a reference-layout state dict into the C model
+descriptors of include/sprc.h and issues one C call per batch on torch's current stream.
+
+torch is used for device memory, streams and the one-time weight repack only; every
+computation of the retrieval path runs in the HIP kernels.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from .config import SprcConfig
+
+_TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rowmap(rows_per_group: int = 0, group_stride: int = 0, group_offset: int = 0) -> L.RowMap:
+    return L.RowMap(rows_per_group, group_stride, group_offset)
+
+
+# --------------------------------------------------------------------------------------------
+# thin operator wrappers (used by the unit parity tests and by Engine)
+# --------------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None, act=L.ACT_NONE, out=None,
+         M=None, amap=None, cmap=None, ldc=None) -> torch.Tensor:
+    lib = L.load()
+    dt = L.SPRC_BF16 if A.dtype == torch.bfloat16 else L.SPRC_F32
+    assert W.dtype == A.dtype and A.is_cuda and A.stride(-1) == 1 and W.stride(-1) == 1
+    N, K = W.shape
+    M = A.shape[0] if M is None else M
+    odt = dt if out_dtype is None else out_dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=_TORCH_DT[odt], device=A.device)
+    g = L.GemmArgs()
+    g.M, g.N, g.K, g.dtype, g.out_dtype, g.act, g.max32 = M, N, K, dt, odt, act, 0
+    g.A, g.lda, g.amap = A.data_ptr(), A.stride(0), amap or rowmap()
+    g.W, g.ldw = W.data_ptr(), W.stride(0)
+    g.bias = _ptr(bias)
+    g.resid, g.ldr = _ptr(resid), (resid.stride(0) if resid is not None else 0)
+    g.C, g.ldc, g.cmap = out.data_ptr(), (out.stride(0) if ldc is None else ldc), cmap or rowmap()
+    L.check(lib.sprc_gemm(C.byref(g), _stream()), "sprc_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype: int, want32=True, want16=True,
+              xmap=None, ymap=None, M=None, y32=None, y16=None):
+    lib = L.load()
+    Mx, D = x.shape
+    M = Mx if M is None else M
+    if want32 and y32 is None:
+        y32 = torch.empty((Mx, D), dtype=torch.float32, device=x.device)
+    if want16 and y16 is None:
+        y16 = torch.empty((Mx, D), dtype=_TORCH_DT[out_dtype], device=x.device)
+    a = L.LayerNormArgs()
+    a.M, a.D, a.out_dtype = M, D, out_dtype
+    a.x, a.ldx, a.xmap = x.data_ptr(), x.stride(0), xmap or rowmap()
+    a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    a.y32, a.ld32, a.ymap = _ptr(y32), D, ymap or rowmap()
+    a.y16, a.ld16 = _ptr(y16), D
+    L.check(lib.sprc_layernorm(C.byref(a), _stream()), "sprc_layernorm")
+    return y32, y16
+
+
+def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=None, out=None):
+    lib = L.load()
+    dt = L.SPRC_BF16 if q.dtype == torch.bfloat16 else L.SPRC_F32
+    if out is None:
+        out = torch.empty((B * Tq, H * head_dim), dtype=q.dtype, device=q.device)
+    a = L.AttentionArgs()
+    a.B, a.H, a.Tq, a.Tk, a.head_dim, a.dtype = B, H, Tq, Tk, head_dim, dt
+    a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv
+    a.out, a.ldo = out.data_ptr(), out.stride(0)
+    a.key_mask, a.scale = _ptr(key_mask), scale
+    L.check(lib.sprc_attention(C.byref(a), _stream()), "sprc_attention")
+    return out
+
+
+def sim_max(fusion: torch.Tensor, feats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sim[nq,N] = max_j <fusion[q], feats[n,j]>; fusion [nq,E], feats [N,32,E] (fp32 or bf16)."""
+    lib = L.load()
+    nq, E = fusion.shape
+    N, J, E2 = feats.shape
+    assert J == 32 and E2 == E and fusion.dtype == feats.dtype and fusion.is_contiguous() and feats.is_contiguous()
+    dt = L.SPRC_BF16 if fusion.dtype == torch.bfloat16 else L.SPRC_F32
+    if out is None:
+        out = torch.empty((nq, N), dtype=torch.float32, device=fusion.device)
+    L.check(lib.sprc_sim_max(fusion.data_ptr(), feats.data_ptr(), out.data_ptr(), out.stride(0), nq, N, E, dt, _stream()),
+            "sprc_sim_max")
+    return out
+
+
+def topk(sim: torch.Tensor, k: int, gidx: Optional[torch.Tensor] = None, idx_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """First k entries of the stable argsort of fl32(1 - sim) per row -> (sim values, int32 indices)."""
+    lib = L.load()
+    assert sim.dtype == torch.float32 and sim.stride(-1) == 1
+    nq, N = sim.shape
+    vals = torch.empty((nq, k), dtype=torch.float32, device=sim.device)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=sim.device)
+    if gidx is not None:
+        assert gidx.dtype == torch.int32 and gidx.is_contiguous() and gidx.shape == sim.shape
+    L.check(lib.sprc_topk(sim.data_ptr(), sim.stride(0), _ptr(gidx), idx_base, nq, N, k, vals.data_ptr(), idx.data_ptr(),
+                          _stream()), "sprc_topk")
+    return vals, idx
+
+
+def rank_of(sim: torch.Tensor, listed: torch.Tensor) -> torch.Tensor:
+    """Position of listed[q,l] in the stable order of row q (int32; -1 where listed < 0)."""
+    lib = L.load()
+    assert sim.dtype == torch.float32 and sim.stride(-1) == 1
+    listed = listed.to(device=sim.device, dtype=torch.int32).contiguous()
+    nq, N = sim.shape
+    out = torch.empty_like(listed)
+    L.check(lib.sprc_rank_of(sim.data_ptr(), sim.stride(0), listed.data_ptr(), nq, N, listed.shape[1], out.data_ptr(),
+                             _stream()), "sprc_rank_of")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+class Engine:
+    """Packed weights + workspaces for one model on one GPU."""
+
+    def __init__(self, cfg: SprcConfig, state_dict: Dict[str, torch.Tensor], device, dtype: str = "bf16",
+                 max_batch: int = 128):
+        self.lib = L.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.SprcError("sprc_amd.Engine needs a GPU device: the HIP kernels are the only compute path")
+        self.dt = L.DTYPES[dtype]
+        self.tdt = _TORCH_DT[self.dt]
+        self.max_batch = max_batch
+        self._keep: List[torch.Tensor] = []
+        self._ws: Dict[str, torch.Tensor] = {}
+        self._pack_vit(state_dict)
+        self._pack_qformer(state_dict)
+
+    # ---- packing -------------------------------------------------------------------------
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _w(self, t: torch.Tensor, k_pad: Optional[int] = None) -> torch.Tensor:
+        t = t.detach().to(device=self.device, dtype=torch.float32)
+        if k_pad is not None and k_pad != t.shape[1]:
+            t = torch.nn.functional.pad(t, (0, k_pad - t.shape[1]))
+        t = t.to(self.tdt).contiguous()
+        self._keep.append(t)
+        return t
+
+    def _lin(self, w: torch.Tensor, b: Optional[torch.Tensor], k_pad: Optional[int] = None) -> L.Linear:
+        return L.Linear(self._w(w, k_pad).data_ptr(), None if b is None else self._f32(b).data_ptr())
+
+    def _pack_vit(self, sd):
+        v = self.cfg.vit
+        p = "visual_encoder."
+        D = v.width
+        kq = 64 if self.dt == L.SPRC_BF16 else 32
+        self.patch_k_pad = (v.patch_k + kq - 1) // kq * kq
+        layers = (L.VitLayer * v.depth)()
+        for i in range(v.depth):
+            ly = layers[i]
+            if v.kind == "eva_g":
+                b = f"{p}blocks.{i}."
+                qkv_b = torch.cat([sd[b + "attn.q_bias"].float(), torch.zeros_like(sd[b + "attn.v_bias"]).float(),
+                                   sd[b + "attn.v_bias"].float()])               # eva_vit.py:120-122
+                names = ("norm1", "norm2", "attn.qkv.weight", "attn.proj", "mlp.fc1", "mlp.fc2")
+                ly.qkv = self._lin(sd[b + names[2]], qkv_b)
+            else:
+                b = f"{p}transformer.resblocks.{i}."
+                names = ("ln_1", "ln_2", "attn.in_proj_weight", "attn.out_proj", "mlp.c_fc", "mlp.c_proj")
+                ly.qkv = self._lin(sd[b + names[2]], sd[b + "attn.in_proj_bias"])
+            ly.ln1_w, ly.ln1_b = self._f32(sd[b + names[0] + ".weight"]).data_ptr(), self._f32(sd[b + names[0] + ".bias"]).data_ptr()
+            ly.ln2_w, ly.ln2_b = self._f32(sd[b + names[1] + ".weight"]).data_ptr(), self._f32(sd[b + names[1] + ".bias"]).data_ptr()
+            ly.proj = self._lin(sd[b + names[3] + ".weight"], sd[b + names[3] + ".bias"])
+            ly.fc1 = self._lin(sd[b + names[4] + ".weight"], sd[b + names[4] + ".bias"])
+            ly.fc2 = self._lin(sd[b + names[5] + ".weight"], sd[b + names[5] + ".bias"])
+        m = L.VitModel()
+        m.dtype, m.width, m.depth, m.heads, m.head_dim, m.mlp = self.dt, D, v.depth, v.heads, v.head_dim, v.mlp
+        m.act = L.ACT_GELU if v.act == "gelu" else L.ACT_QUICKGELU
+        m.tokens, m.patch_size, m.image, m.patch_k_pad = v.tokens, v.patch, v.image, self.patch_k_pad
+        m.has_ln_pre, m.ln_eps, m.ln_vision_eps = int(v.ln_pre), v.ln_eps, self.cfg.ln_vision_eps
+        if v.kind == "eva_g":
+            m.patch = self._lin(sd[p + "patch_embed.proj.weight"].reshape(D, -1), sd[p + "patch_embed.proj.bias"], self.patch_k_pad)
+            m.cls = self._f32(sd[p + "cls_token"].reshape(D)).data_ptr()
+            m.pos = self._f32(sd[p + "pos_embed"].reshape(v.tokens, D)).data_ptr()
+        else:
+            m.patch = self._lin(sd[p + "conv1.weight"].reshape(D, -1), None, self.patch_k_pad)
+            m.cls = self._f32(sd[p + "class_embedding"].reshape(D)).data_ptr()
+            m.pos = self._f32(sd[p + "positional_embedding"].reshape(v.tokens, D)).data_ptr()
+            m.ln_pre_w = self._f32(sd[p + "ln_pre.weight"]).data_ptr()
+            m.ln_pre_b = self._f32(sd[p + "ln_pre.bias"]).data_ptr()
+        m.ln_vision_w = self._f32(sd["ln_vision.weight"]).data_ptr()
+        m.ln_vision_b = self._f32(sd["ln_vision.bias"]).data_ptr()
+        m.layers = C.cast(layers, C.POINTER(L.VitLayer))
+        self._vit_layers, self.vit = layers, m
+
+    def _pack_qformer(self, sd):
+        q = self.cfg.qformer
+        p = "Qformer.bert."
+        layers = (L.QfLayer * q.layers)()
+        ckv_w, ckv_b, n_cross = [], [], 0
+
+        def ln(prefix):
+            return self._f32(sd[prefix + ".weight"]).data_ptr(), self._f32(sd[prefix + ".bias"]).data_ptr()
+
+        for l in range(q.layers):
+            b = f"{p}encoder.layer.{l}."
+            ly = layers[l]
+            a = b + "attention."
+            ly.qkv = self._lin(torch.cat([sd[a + "self.query.weight"], sd[a + "self.key.weight"], sd[a + "self.value.weight"]]).float(),
+                               torch.cat([sd[a + "self.query.bias"], sd[a + "self.key.bias"], sd[a + "self.value.bias"]]).float())
+            ly.attn_out = self._lin(sd[a + "output.dense.weight"], sd[a + "output.dense.bias"])
+            ly.attn_ln_w, ly.attn_ln_b = ln(a + "output.LayerNorm")
+            if l % q.cross_freq == 0:
+                c = b + "crossattention."
+                ly.has_cross, ly.cross_index = 1, n_cross
+                ly.cq = self._lin(sd[c + "self.query.weight"], sd[c + "self.query.bias"])
+                ckv_w += [sd[c + "self.key.weight"].float(), sd[c + "self.value.weight"].float()]
+                ckv_b += [sd[c + "self.key.bias"].float(), sd[c + "self.value.bias"].float()]
+                ly.cross_out = self._lin(sd[c + "output.dense.weight"], sd[c + "output.dense.bias"])
+                ly.cross_ln_w, ly.cross_ln_b = ln(c + "output.LayerNorm")
+                n_cross += 1
+            ly.ffn_t_in = self._lin(sd[b + "intermediate.dense.weight"], sd[b + "intermediate.dense.bias"])
+            ly.ffn_t_out = self._lin(sd[b + "output.dense.weight"], sd[b + "output.dense.bias"])
+            ly.ffn_t_ln_w, ly.ffn_t_ln_b = ln(b + "output.LayerNorm")
+            ly.ffn_q_in = self._lin(sd[b + "intermediate_query.dense.weight"], sd[b + "intermediate_query.dense.bias"])
+            ly.ffn_q_out = self._lin(sd[b + "output_query.dense.weight"], sd[b + "output_query.dense.bias"])
+            ly.ffn_q_ln_w, ly.ffn_q_ln_b = ln(b + "output_query.LayerNorm")
+        m = L.QformerModel()
+        m.dtype, m.hidden, m.n_layers, m.heads, m.head_dim, m.ffn = self.dt, q.hidden, q.layers, q.heads, q.head_dim, q.ffn
+        m.num_query, m.enc_width, m.embed_dim, m.max_txt, m.n_cross = q.num_query, self.cfg.vit.width, self.cfg.embed_dim, self.cfg.max_txt_len, n_cross
+        m.ln_eps = q.ln_eps
+        m.word_emb = self._f32(sd[p + "embeddings.word_embeddings.weight"]).data_ptr()
+        m.pos_emb = self._f32(sd[p + "embeddings.position_embeddings.weight"]).data_ptr()
+        m.emb_ln_w, m.emb_ln_b = ln(p + "embeddings.LayerNorm")
+        m.query_tokens = self._f32(sd["query_tokens"].reshape(q.num_query, q.hidden)).data_ptr()
+        m.ckv_all = self._lin(torch.cat([w.to(self.device) for w in ckv_w]), torch.cat([b_.to(self.device) for b_ in ckv_b]))
+        m.vision_proj = self._lin(sd["vision_proj.weight"], sd["vision_proj.bias"])
+        m.text_proj = self._lin(sd["text_proj.weight"], sd["text_proj.bias"])
+        m.layers = C.cast(layers, C.POINTER(L.QfLayer))
+        self._qf_layers, self.qf = layers, m
+
+    # ---- workspaces ------------------------------------------------------------------------
+    def _workspace(self, kind: str, B: int) -> torch.Tensor:
+        fn = self.lib.sprc_vit_workspace_bytes if kind == "vit" else self.lib.sprc_qformer_workspace_bytes
+        need = int(fn(C.byref(self.vit if kind == "vit" else self.qf), B))
+        ws = self._ws.get(kind)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[kind] = ws
+        return ws
+
+    # ---- forward passes ----------------------------------------------------------------------
+    def vit_forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """raw[B,257,D] fp32 = ln_vision(ViT(images))."""
+        v = self.cfg.vit
+        images = images.to(device=self.device, dtype=torch.float32).contiguous()
+        B = images.shape[0]
+        if tuple(images.shape[1:]) != (3, v.image, v.image):
+            raise ValueError(f"Input image size ({images.shape[2]}*{images.shape[3]}) doesn't match model ({v.image}*{v.image}).")
+        raw = out if out is not None else torch.empty((B, v.tokens, v.width), dtype=torch.float32, device=self.device)
+        for s in range(0, B, self.max_batch):
+            n = min(self.max_batch, B - s)
+            ws = self._workspace("vit", n)
+            L.check(self.lib.sprc_vit_forward(C.byref(self.vit), images[s:s + n].data_ptr(), n, raw[s:s + n].data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream()), "sprc_vit_forward")
+        return raw
+
+    def qformer_image(self, raw: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """feats[B,32,E] fp32 (unit rows) + compute-dtype copy (bf16 mode)."""
+        raw = raw.to(device=self.device, dtype=torch.float32).contiguous()
+        B, E, Lq = raw.shape[0], self.cfg.embed_dim, self.cfg.qformer.num_query
+        feats = torch.empty((B, Lq, E), dtype=torch.float32, device=self.device)
+        f16 = torch.empty((B, Lq, E), dtype=self.tdt, device=self.device) if self.dt == L.SPRC_BF16 else None
+        for s in range(0, B, self.max_batch):
+            n = min(self.max_batch, B - s)
+            ws = self._workspace("qf", n)
+            L.check(self.lib.sprc_qformer_image(C.byref(self.qf), raw[s:s + n].data_ptr(), n, feats[s:s + n].data_ptr(),
+                                                None if f16 is None else f16[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                _stream()), "sprc_qformer_image")
+        return feats, f16
+
+    def qformer_fuse(self, ref_embeds: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        """fusion[B,E] fp32 (unit rows) + compute-dtype copy (bf16 mode)."""
+        ref = ref_embeds.to(device=self.device, dtype=torch.float32).contiguous()
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        B, E = ref.shape[0], self.cfg.embed_dim
+        if ids.shape != (B, self.cfg.max_txt_len) or mask.shape != ids.shape:
+            raise ValueError(f"input_ids/attention_mask must be [{B},{self.cfg.max_txt_len}]")
+        if int(ids.min()) < 0 or int(ids.max()) >= self.cfg.qformer.vocab:
+            raise IndexError("token id out of range")
+        fusion = torch.empty((B, E), dtype=torch.float32, device=self.device)
+        f16 = torch.empty((B, E), dtype=self.tdt, device=self.device) if self.dt == L.SPRC_BF16 else None
+        for s in range(0, B, self.max_batch):
+            n = min(self.max_batch, B - s)
+            ws = self._workspace("qf", n)
+            L.check(self.lib.sprc_qformer_fuse(C.byref(self.qf), ref[s:s + n].data_ptr(), ref.shape[1], ids[s:s + n].data_ptr(),
+                                               mask[s:s + n].data_ptr(), n, fusion[s:s + n].data_ptr(),
+                                               None if f16 is None else f16[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
+                                               _stream()), "sprc_qformer_fuse")
+        return fusion, f16

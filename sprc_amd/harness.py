@@ -1,0 +1,208 @@
+"""Evaluation harness of the retrieval path: gallery feature extraction, query prediction loops and
+Recall@K metrics, with the reference's function names, arguments and return values
+(src/utils.py:46-77,141-148; src/validate_blip.py:24-57,149-207,232-285,359-410;
+src/cirr_test_submission.py:61-190) so the reference's scripts can import them unchanged.
+
+What differs is HOW the metrics are computed: the reference sorts every row of `1 - sim` with
+torch.argsort and then runs O(nq*N) numpy string comparisons (validate_blip.py:253-271).  Here the
+names are mapped to gallery indices once and the ranks come from the HIP ranking kernels
+(sprc_rank_of / sprc_topk): integer-exact, under the stable tie rule (fl32(1-sim), index), with no
+full sort and no nq x N host traffic.
+"""
+from __future__ import annotations
+
+from operator import itemgetter
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from . import engine as E
+from .processors import fiq_compose_caption
+
+try:  # progress bars as in the reference, optional
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    def tqdm(x, **k):
+        return x
+
+
+def collate_fn(batch: list):
+    """Drop `None` items (datasets swallow per-item errors, data_utils.py:191-192,277-278; utils.py:141-148)."""
+    batch = [b for b in batch if b is not None]
+    return torch.utils.data.dataloader.default_collate(batch)
+
+
+def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, batch_size: int = 64, num_workers: int = 2):
+    """-> ((feats[N,32,256], raw[N,257,D]), names[N])   (src/utils.py:46-77)"""
+    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True, collate_fn=collate_fn)
+    feats, raws, names = [], [], []
+    split = getattr(dataset, "split", "")
+    print(f"extracting {type(dataset).__name__} {split} index features")
+    dev = blip_model.device
+    for batch_names, images in tqdm(loader):
+        images = images.to(dev, non_blocking=True)
+        f, r = blip_model.extract_target_features(images, mode="mean")
+        if save_memory:
+            f, r = f.cpu(), r.cpu()
+        feats.append(f)
+        raws.append(r)
+        names.extend(batch_names)
+    return (torch.vstack(feats), torch.vstack(raws)), names
+
+
+def _stack_refs(name_to_feat: Dict[str, torch.Tensor], names: Sequence[str]) -> torch.Tensor:
+    if len(names) == 1:
+        return name_to_feat[names[0]].unsqueeze(0)
+    return torch.stack(itemgetter(*names)(name_to_feat))
+
+
+# ---- CIRR validation ---------------------------------------------------------------------------------
+def generate_cirr_val_predictions(blip_model, relative_val_dataset, index_names: List[str], index_features, txt_processors,
+                                  batch_size: int = 32, num_workers: int = 2):
+    """-> (sim[nq,N], reference_names, target_names, group_members, captions)   (validate_blip.py:359-410)"""
+    print("Compute CIRR validation predictions")
+    loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True,
+                        collate_fn=collate_fn)
+    name_to_feat = dict(zip(index_names, index_features[1]))
+    sims, target_names, group_members, reference_names, captions_all = [], [], [], [], []
+    dev = blip_model.device
+    for batch_refs, batch_tgts, captions, batch_groups in tqdm(loader):
+        batch_groups = np.array(batch_groups).T.tolist()
+        captions = [txt_processors["eval"](c) for c in captions]
+        ref_feats = _stack_refs(name_to_feat, batch_refs).to(dev)
+        sims.append(blip_model.inference(ref_feats, index_features[0].to(dev), captions))
+        captions_all += captions
+        target_names.extend(batch_tgts)
+        group_members.extend(batch_groups)
+        reference_names.extend(batch_refs)
+    return torch.vstack(sims), reference_names, target_names, group_members, captions_all
+
+
+def _pct(hits: np.ndarray) -> float:
+    # reference: (torch.sum(labels[:, :k]) / len(labels)).item() * 100 -- an fp32 division
+    return float(np.float32(hits.sum()) / np.float32(len(hits))) * 100
+
+
+def cirr_metrics_from_sim(sim: torch.Tensor, ref_idx, tgt_idx, group_idx) -> Tuple[float, ...]:
+    """Recall@{1,5,10,50} with the reference image removed + subset Recall@{1,2,3} from exact ranks."""
+    ref_idx, tgt_idx, group_idx = (np.asarray(a, dtype=np.int64) for a in (ref_idx, tgt_idx, group_idx))
+    listed = np.concatenate([tgt_idx[:, None], ref_idx[:, None], group_idx], axis=1)
+    ranks = E.rank_of(sim.contiguous(), torch.from_numpy(listed)).cpu().numpy().astype(np.int64)
+    r_t, r_ref, r_g = ranks[:, 0], ranks[:, 1], ranks[:, 2:]
+    assert (tgt_idx != ref_idx).all() and (r_t >= 0).all(), "every query needs its target in the gallery, distinct from the reference"
+    rank_t = r_t - (r_ref < r_t)                                        # validate_blip.py:258-261: drop the reference
+    in_group = (group_idx == tgt_idx[:, None]).sum(1)
+    assert (in_group == 1).all(), "target must appear exactly once among the group members"     # :273-274
+    member_ok = group_idx != ref_idx[:, None]
+    pos_in_group = ((r_g < r_t[:, None]) & member_ok).sum(1)            # :268-271
+    return (_pct(pos_in_group < 1), _pct(pos_in_group < 2), _pct(pos_in_group < 3),
+            _pct(rank_t < 1), _pct(rank_t < 5), _pct(rank_t < 10), _pct(rank_t < 50))
+
+
+def compute_cirr_val_metrics(relative_val_dataset, blip_model, index_features, index_names: List[str], txt_processors):
+    """-> (group_recall@1, @2, @3, recall@1, @5, @10, @50)   (validate_blip.py:232-285)"""
+    sim, reference_names, target_names, group_members, _ = generate_cirr_val_predictions(
+        blip_model, relative_val_dataset, index_names, index_features, txt_processors)
+    print("Compute CIRR validation metrics")
+    n2i = {n: i for i, n in enumerate(index_names)}
+    ref = [n2i[n] for n in reference_names]
+    tgt = [n2i[n] for n in target_names]
+    grp = [[n2i.get(n, -1) for n in g] for g in group_members]
+    return cirr_metrics_from_sim(sim, ref, tgt, grp)
+
+
+# ---- FashionIQ validation ----------------------------------------------------------------------------
+def generate_fiq_val_predictions(blip_model, relative_val_dataset, index_names: List[str], index_features, txt_processors,
+                                 save_memory: bool = False, batch_size: int = 16, num_workers: int = 4):
+    """-> (sim[nq,N], target_names, reference_names, captions)   (validate_blip.py:149-207)"""
+    print(f"Compute FashionIQ {getattr(relative_val_dataset, 'dress_types', '')} validation predictions")
+    loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True,
+                        collate_fn=collate_fn, shuffle=False)
+    name_to_feat = dict(zip(index_names, index_features[-1]))
+    sims, target_names, reference_names, captions_all = [], [], [], []
+    dev = blip_model.device
+    for batch_refs, batch_tgts, captions in tqdm(loader):
+        flat = np.array(captions).T.flatten().tolist()
+        composed = [fiq_compose_caption(flat[i], flat[i + 1]) for i in range(0, len(flat), 2)]     # :180-184
+        composed = [txt_processors["eval"](c) for c in composed]
+        ref_feats = _stack_refs(name_to_feat, batch_refs).to(dev)
+        sims.append(blip_model.inference(ref_feats, index_features[0].to(dev), composed))
+        captions_all += composed
+        target_names.extend(batch_tgts)
+        reference_names.extend(batch_refs)
+    return torch.vstack(sims), target_names, reference_names, captions_all
+
+
+def fiq_metrics_from_sim(sim: torch.Tensor, tgt_idx) -> Tuple[float, float]:
+    tgt_idx = np.asarray(tgt_idx, dtype=np.int64)
+    r = E.rank_of(sim.contiguous(), torch.from_numpy(tgt_idx[:, None])).cpu().numpy()[:, 0]
+    assert (r >= 0).all(), "every query needs its target in the gallery"              # validate_blip.py:51
+    return _pct(r < 10), _pct(r < 50)
+
+
+def compute_fiq_val_metrics(relative_val_dataset, blip_model, index_features, index_names: List[str], txt_processors,
+                            save_memory: bool = False) -> Tuple[float, float]:
+    """-> (recall@10, recall@50); the reference image is NOT removed   (validate_blip.py:24-57)"""
+    sim, target_names, _, _ = generate_fiq_val_predictions(blip_model, relative_val_dataset, index_names, index_features,
+                                                           txt_processors, save_memory)
+    print(f"Compute FashionIQ {getattr(relative_val_dataset, 'dress_types', '')} validation metrics")
+    n2i = {n: i for i, n in enumerate(index_names)}
+    return fiq_metrics_from_sim(sim, [n2i[n] for n in target_names])
+
+
+# ---- CIRR test submission ----------------------------------------------------------------------------
+def generate_cirr_test_predictions(blip_model, relative_test_dataset, index_names: List[str], index_features, txt_processors,
+                                   batch_size: int = 32, num_workers: int = 4):
+    """-> (sim, reference_names, group_members, pairs_id, captions, name_to_feat)   (cirr_test_submission.py:135-190)"""
+    print("Compute CIRR test predictions")
+    loader = DataLoader(dataset=relative_test_dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True)
+    name_to_feat = dict(zip(index_names, index_features[1]))
+    pairs_id, group_members, reference_names, sims, captions_all = [], [], [], [], []
+    dev = blip_model.device
+    for batch_pairs, batch_refs, captions, batch_groups in tqdm(loader):
+        batch_groups = np.array(batch_groups).T.tolist()
+        captions = [txt_processors["eval"](c) for c in captions]
+        ref_feats = _stack_refs(name_to_feat, batch_refs).to(dev)     # (the reference's B==1 branch has an `.unqueeze` typo, :175)
+        sims.append(blip_model.inference(ref_feats, index_features[0].to(dev), captions))
+        captions_all += captions
+        group_members.extend(batch_groups)
+        reference_names.extend(batch_refs)
+        pairs_id.extend(batch_pairs)
+    return torch.vstack(sims), reference_names, group_members, pairs_id, captions_all, name_to_feat
+
+
+def cirr_test_dicts_from_sim(sim: torch.Tensor, ref_idx, group_idx, pairs_id, index_names: Sequence[str]):
+    """top-50 names (reference removed) and top-3 subset names per pair id, from top-51 + 6 exact ranks."""
+    ref_idx, group_idx = np.asarray(ref_idx, dtype=np.int64), np.asarray(group_idx, dtype=np.int64)
+    names = np.asarray(index_names)
+    N = sim.shape[1]
+    k = min(51, 64)
+    _, idx = E.topk(sim.contiguous(), k)
+    idx = idx.cpu().numpy()
+    g_rank = E.rank_of(sim.contiguous(), torch.from_numpy(group_idx)).cpu().numpy().astype(np.int64)
+    top, sub = {}, {}
+    for q, pid in enumerate(pairs_id):
+        row = [i for i in idx[q] if i >= 0 and i != ref_idx[q]][: min(50, N - 1)]       # cirr_test_submission.py:116-120,127
+        top[str(int(pid))] = names[row].tolist()
+        members = [(g_rank[q, j], group_idx[q, j]) for j in range(group_idx.shape[1])
+                   if group_idx[q, j] >= 0 and group_idx[q, j] != ref_idx[q]]
+        members.sort()
+        sub[str(int(pid))] = names[[m[1] for m in members[:3]]].tolist()                 # :122-124,129-130
+    return top, sub
+
+
+def generate_cirr_test_dicts(relative_test_dataset, blip_model, index_features, index_names: List[str], txt_processors,
+                             rerank=False):
+    """-> (pairid -> top-50 names, pairid -> top-3 subset names)   (cirr_test_submission.py:61-132)"""
+    if rerank:
+        raise NotImplementedError("stage-2 rerank needs `inference_rerank`, which blip2_cir_align_prompt does not define "
+                                  "(cirr_test_submission.py:88-112; SURVEY.md section 8(f) N2)")
+    sim, reference_names, group_members, pairs_id, _, _ = generate_cirr_test_predictions(
+        blip_model, relative_test_dataset, index_names, index_features, txt_processors)
+    print("Compute CIRR prediction dicts")
+    n2i = {n: i for i, n in enumerate(index_names)}
+    ref = [n2i[n] for n in reference_names]
+    grp = [[n2i.get(n, -1) for n in g] for g in group_members]
+    return cirr_test_dicts_from_sim(sim, ref, grp, pairs_id, index_names)

@@ -1,0 +1,184 @@
+"""`Blip2QformerCirAlignPrompt` -- the SPRC model protocol on the MI355X HIP engine.
+
+Drop-in for lavis/models/blip2_models/blip2_qformer_cir_align_prompt.py on the retrieval path:
+same class name (it is the checkpoint key, src/utils.py:218-222; src/blip_validate.py:107-109), same
+registry name ("blip2_cir_align_prompt", align_prompt.py:25), same state-dict keys
+(SURVEY.md section 8(b)), and the two methods the evaluation harness calls:
+
+    extract_target_features(image, mode="mean") -> (feats[B,32,256], raw[B,257,D])     align_prompt.py:364-386
+    inference(reference_embeds, target_feats, text) -> sim[B,N]                        align_prompt.py:312-361
+
+All compute goes through libsprc_hip.so (sprc_amd/engine.py); there is no torch/CPU fallback:
+calling these methods on a CPU-resident model raises.
+
+Deliberate differences from the reference (documented in DESIGN.md):
+  * eval semantics always (dropout = identity).  The reference's CIRR scripts leave the Q-Former in
+    train mode, which makes their features stochastic.
+  * `inference` always returns a 2-D [B,N] tensor (the reference's `.squeeze()` collapses B=1 / N=1).
+  * `forward` (the three training losses, align_prompt.py:95-200) is out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import synth
+from .config import MODEL_TYPES, SprcConfig, get_config
+
+
+class _Node(nn.Module):
+    """Bare container so that parameters get the reference's dotted state-dict names."""
+
+
+def _register(root: nn.Module, dotted: str, shape, device="cpu") -> None:
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape, device=device), requires_grad=False))
+
+
+class Blip2QformerCirAlignPrompt(nn.Module):
+    PRETRAINED_MODEL_CONFIG_DICT = {k: k for k in MODEL_TYPES}     # align_prompt.py:38-42 ("coco" has no CIR use)
+
+    def __init__(self, model_type: str = "pretrain", compute_dtype: str = "bf16", rank_dtype: str = "fp32",
+                 cfg: Optional[SprcConfig] = None, max_batch: int = 128, tokenizer=None, device="cpu"):
+        super().__init__()
+        self.cfg = cfg if cfg is not None else get_config(model_type)
+        self.compute_dtype, self.rank_dtype, self.max_batch = compute_dtype, rank_dtype, max_batch
+        self.max_txt_len = self.cfg.max_txt_len
+        for name, shape, _ in synth.param_specs(self.cfg):
+            _register(self, name, shape, device)
+        self.register_parameter("temp", nn.Parameter(0.07 * torch.ones([], device=device), requires_grad=False))
+        self._engine: Optional[E.Engine] = None
+        self._tokenizer = tokenizer
+        self.training = False
+
+    # ---- construction helpers (lavis/models/base_model.py:58-80) --------------------------------
+    @classmethod
+    def from_pretrained(cls, model_type: str, **kw) -> "Blip2QformerCirAlignPrompt":
+        assert model_type in cls.PRETRAINED_MODEL_CONFIG_DICT, "Unknown model type {}".format(model_type)
+        return cls(model_type=model_type, **kw)
+
+    @classmethod
+    def from_config(cls, cfg: dict) -> "Blip2QformerCirAlignPrompt":
+        vit = cfg.get("vit_model", "eva_clip_g")                  # align_prompt.py:502-529
+        return cls(model_type="pretrain" if vit == "eva_clip_g" else "pretrain_vitL")
+
+    def init_synthetic(self, seed: int = 0) -> "Blip2QformerCirAlignPrompt":
+        """Seeded random weights (no checkpoint is reachable offline; see sprc_amd/synth.py)."""
+        dev = self.device
+        gen_dev = "cpu" if dev.type == "cpu" else str(dev)
+        with torch.no_grad():
+            params = dict(self.named_parameters())
+            for name, t in synth.iter_state_dict(self.cfg, seed, device=gen_dev):
+                params[name].copy_(t)
+        self._engine = None
+        return self
+
+    # ---- nn.Module plumbing ---------------------------------------------------------------------
+    @property
+    def device(self) -> torch.device:
+        return list(self.parameters())[0].device                 # base_model.py:25-27
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        self._engine = None
+        return super().load_state_dict(state_dict, strict=strict)
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode: bool = True):
+        self.training = False                                     # inference engine: eval semantics only
+        return self
+
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            from .tokenizer import BertWordPieceTokenizer
+            self._tokenizer = BertWordPieceTokenizer()
+        return self._tokenizer
+
+    @tokenizer.setter
+    def tokenizer(self, tok):
+        self._tokenizer = tok
+
+    def engine(self) -> E.Engine:
+        if self._engine is None:
+            if self.device.type != "cuda":
+                raise L.SprcError("Blip2QformerCirAlignPrompt runs on the MI355X HIP engine only; move the model to a "
+                                  "GPU with .to('cuda') (there is no CPU fallback)")
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._engine = E.Engine(self.cfg, sd, self.device, dtype=self.compute_dtype, max_batch=self.max_batch)
+        return self._engine
+
+    # ---- the protocol ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def extract_target_features(self, image: torch.Tensor, mode: str = "mean") -> Tuple[torch.Tensor, torch.Tensor]:
+        eng = self.engine()
+        raw = eng.vit_forward(image)
+        feats, _ = eng.qformer_image(raw)
+        return feats, raw
+
+    @torch.no_grad()
+    def fuse(self, reference_embeds: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """fusion_feats[B,256]: the query side of `inference` with pre-tokenised text."""
+        fusion, _ = self.engine().qformer_fuse(reference_embeds, input_ids, attention_mask)
+        return fusion
+
+    @torch.no_grad()
+    def similarity(self, fusion: torch.Tensor, target_feats: torch.Tensor) -> torch.Tensor:
+        dev = self.device
+        fusion = fusion.to(device=dev, dtype=torch.float32).contiguous()
+        target_feats = target_feats.to(device=dev, dtype=torch.float32).contiguous()
+        if target_feats.dim() != 3 or target_feats.shape[1] != 32:
+            raise ValueError("target_feats must be [N,32,embed_dim]")
+        if self.rank_dtype == "bf16":
+            return E.sim_max(fusion.to(torch.bfloat16), target_feats.to(torch.bfloat16))
+        return E.sim_max(fusion, target_feats)
+
+    @torch.no_grad()
+    def inference_ids(self, reference_embeds, target_feats, input_ids, attention_mask) -> torch.Tensor:
+        return self.similarity(self.fuse(reference_embeds, input_ids, attention_mask), target_feats)
+
+    @torch.no_grad()
+    def inference(self, reference_embeds: torch.Tensor, target_feats: torch.Tensor, text: List[str]) -> torch.Tensor:
+        if isinstance(text, str):
+            text = [text]
+        if len(text) != reference_embeds.shape[0]:
+            raise ValueError("one caption per reference image is required")
+        tok = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_txt_len,
+                             return_tensors="pt").to(self.device)
+        return self.inference_ids(reference_embeds, target_feats, tok.input_ids, tok.attention_mask)
+
+    def forward(self, samples):
+        raise NotImplementedError("training forward (align_prompt.py:95-200) is outside the retrieval hot path "
+                                  "(SURVEY.md section 8(f) N4)")
+
+
+# ---- registry + loader (lavis/common/registry.py:83-110, lavis/models/__init__.py:204-249) -----------
+_MODEL_REGISTRY: Dict[str, type] = {"blip2_cir_align_prompt": Blip2QformerCirAlignPrompt}
+
+
+def get_model_class(name: str):
+    if name not in _MODEL_REGISTRY:
+        raise KeyError(f"model '{name}' is not registered (available: {sorted(_MODEL_REGISTRY)}); the reference "
+                       f"scripts' default --blip-model-name points at sources it does not ship (SURVEY.md 2 row 25)")
+    return _MODEL_REGISTRY[name]
+
+
+def load_model_and_preprocess(name: str, model_type: str, is_eval: bool = False, device="cpu", **model_kw):
+    """-> (model, vis_processors, txt_processors), as lavis.models.load_model_and_preprocess."""
+    from .processors import BlipCaptionProcessor
+    model = get_model_class(name).from_pretrained(model_type=model_type, **model_kw)
+    if is_eval:
+        model.eval()
+    txt = {"train": BlipCaptionProcessor(), "eval": BlipCaptionProcessor()}
+    return model.to(device), {"train": None, "eval": None}, txt

@@ -1,0 +1,267 @@
+"""GPU parity of every building-block operator of libsprc_hip.so (called through the C ABI).
+
+References are plain fp32/fp64 torch expressions evaluated on the CPU on the same seeded inputs;
+inputs are asymmetric random (never symmetric/identity) so operand or output transposes show.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from sprc_amd import _lib as L  # noqa: E402
+from sprc_amd import engine as E  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(257 * 2, 1408, 1408), (100, 96, 64), (128, 128, 128), (300, 4224, 1408),
+                                   (514, 1408, 6144), (64, 256, 768), (1, 128, 64), (129, 130, 192)])
+def test_gemm_bf16(M, N, K):
+    A, W, b = _bf(_rand((M, K), 1)), _bf(_rand((N, K), 2, 0.05)), _rand((N,), 3)
+    ref = A.float().double() @ W.float().double().t() + b.double()
+    out = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), out_dtype=L.SPRC_F32).cpu()
+    torch.testing.assert_close(out.double(), ref, atol=2e-3 * math.sqrt(K / 64), rtol=1e-4)
+    out16 = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), out_dtype=L.SPRC_BF16).cpu()
+    torch.testing.assert_close(out16.float(), ref.float().to(torch.bfloat16).float(), atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(257, 1408, 1408), (70, 96, 32), (130, 256, 768), (33, 128, 608)])
+def test_gemm_f32(M, N, K):
+    A, W, b = _rand((M, K), 4), _rand((N, K), 5, 0.05), _rand((N,), 6)
+    ref = A.double() @ W.double().t() + b.double()
+    out = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), out_dtype=L.SPRC_F32).cpu()
+    torch.testing.assert_close(out.double(), ref, atol=5e-5 * math.sqrt(K / 32), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_GELU, L.ACT_QUICKGELU])
+def test_gemm_epilogues(dtype, act):
+    M, N, K = 200, 384, 256
+    A, W, b, r = _rand((M, K), 7), _rand((N, K), 8, 0.1), _rand((N,), 9), _rand((M, N), 10)
+    if dtype == "bf16":
+        A, W = _bf(A), _bf(W)
+    z = A.float().double() @ W.float().double().t() + b.double()
+    if act == L.ACT_GELU:
+        z = torch.nn.functional.gelu(z)
+    elif act == L.ACT_QUICKGELU:
+        z = z * torch.sigmoid(1.702 * z)
+    ref = z + r.double()
+    rd = r.to(DEV)
+    out = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), resid=rd, out_dtype=L.SPRC_F32, act=act).cpu()
+    torch.testing.assert_close(out.double(), ref, atol=3e-3 if dtype == "bf16" else 1e-4, rtol=1e-4)
+    # in-place residual (C aliases resid), as the ViT/Q-Former residual stream uses it
+    E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), resid=rd, out_dtype=L.SPRC_F32, act=act, out=rd)
+    torch.testing.assert_close(rd.cpu().double(), ref, atol=3e-3 if dtype == "bf16" else 1e-4, rtol=1e-4)
+
+
+def test_gemm_rowmaps():
+    # A rows = "rows [32:64] of every 64-row group"; C rows = "rows [:32] of every 64-row group"
+    Bn, K, N = 5, 128, 256
+    A, W = _bf(_rand((Bn * 64, K), 11)), _bf(_rand((N, K), 12, 0.1))
+    sel = torch.cat([torch.arange(g * 64 + 32, g * 64 + 64) for g in range(Bn)])
+    dst = torch.cat([torch.arange(g * 64, g * 64 + 32) for g in range(Bn)])
+    ref = A[sel].float() @ W.float().t()
+    out = torch.full((Bn * 64, N), 7.0, dtype=torch.float32, device=DEV)
+    E.gemm(A.to(DEV), W.to(DEV), out_dtype=L.SPRC_F32, out=out, M=Bn * 32, amap=E.rowmap(32, 64, 32), cmap=E.rowmap(32, 64, 0))
+    out = out.cpu()
+    torch.testing.assert_close(out[dst], ref, atol=2e-3, rtol=1e-4)
+    rest = torch.ones(Bn * 64, dtype=torch.bool)
+    rest[dst] = False
+    assert torch.all(out[rest] == 7.0)
+    # single-row groups: "row 32 of every sample" (the text [CLS] row of align_prompt.py:349)
+    out1 = E.gemm(A.to(DEV), W.to(DEV), out_dtype=L.SPRC_F32, M=Bn, amap=E.rowmap(1, 64, 32),
+                  out=torch.empty((Bn, N), dtype=torch.float32, device=DEV)).cpu()
+    torch.testing.assert_close(out1, A[32::64].float() @ W.float().t(), atol=2e-3, rtol=1e-4)
+
+
+def test_gemm_rejects_bad_arguments():
+    A, W = _bf(_rand((8, 48), 1)).to(DEV), _bf(_rand((8, 48), 2)).to(DEV)
+    with pytest.raises(L.SprcError, match="multiple"):
+        E.gemm(A, W)                     # K = 48 not a multiple of 64
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("nq,N", [(5, 7), (64, 256), (33, 130)])
+def test_sim_max(dtype, nq, N):
+    f = torch.nn.functional.normalize(_rand((nq, 256), 20), dim=-1)
+    G = torch.nn.functional.normalize(_rand((N, 32, 256), 21), dim=-1)
+    if dtype == "bf16":
+        f, G = _bf(f), _bf(G)
+    ref = (f.float().double() @ G.float().double().reshape(N * 32, 256).t()).view(nq, N, 32).max(-1).values
+    sim = E.sim_max(f.to(DEV).contiguous(), G.to(DEV).contiguous()).cpu()
+    torch.testing.assert_close(sim.double(), ref, atol=2e-6 if dtype == "f32" else 1e-5, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,eps", [(1408, 1e-6), (1024, 1e-5), (768, 1e-12), (256, 1e-5)])
+def test_layernorm(D, eps):
+    M = 77
+    x, g, b = _rand((M, D), 30, 3.0) + 0.5, _rand((D,), 31) * 0.1 + 1, _rand((D,), 32) * 0.1
+    ref = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), eps)
+    y32, y16 = E.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), eps, L.SPRC_BF16)
+    torch.testing.assert_close(y32.cpu().double(), ref, atol=2e-6 * 3, rtol=1e-5)
+    assert torch.equal(y16.cpu(), y32.cpu().to(torch.bfloat16))
+    # row maps: normalise rows [32:64] of each 64-row group in place
+    xm = _rand((3 * 64, D), 33).to(DEV)
+    before = xm.clone()
+    E.layernorm(xm, g.to(DEV), b.to(DEV), eps, L.SPRC_F32, want16=False, xmap=E.rowmap(32, 64, 32), ymap=E.rowmap(32, 64, 32),
+                M=3 * 32, y32=xm)
+    sel = torch.cat([torch.arange(gp * 64 + 32, gp * 64 + 64) for gp in range(3)])
+    ref2 = before.cpu().clone()
+    ref2[sel] = torch.nn.functional.layer_norm(before.cpu()[sel], (D,), g, b, eps)
+    torch.testing.assert_close(xm.cpu(), ref2, atol=1e-5, rtol=1e-5)
+
+
+def _attn_ref(q, k, v, scale, mask=None):
+    s = (q.double() @ k.double().transpose(-1, -2)) * scale
+    if mask is not None:
+        s = s + mask[:, None, None, :].double()
+    return (torch.softmax(s, dim=-1) @ v.double())
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("B,H,Tq,Tk,dh,masked", [(2, 16, 257, 257, 88, False), (3, 12, 64, 64, 64, True),
+                                                 (2, 12, 32, 257, 64, False), (2, 16, 257, 257, 64, False),
+                                                 (1, 12, 32, 32, 64, False), (2, 3, 40, 70, 88, True)])
+def test_attention(dtype, B, H, Tq, Tk, dh, masked):
+    D = H * dh
+    q, k, v = _rand((B, Tq, D), 40), _rand((B, Tk, D), 41), _rand((B, Tk, D), 42)
+    if dtype == "bf16":
+        q, k, v = _bf(q), _bf(k), _bf(v)
+    mask = None
+    if masked:
+        keep = torch.ones(B, Tk)
+        for b in range(B):
+            keep[b, Tk - 3 - 5 * b:] = 0
+        mask = (1.0 - keep) * -10000.0
+    scale = dh ** -0.5
+    ref = _attn_ref(q.float().view(B, Tq, H, dh).transpose(1, 2), k.float().view(B, Tk, H, dh).transpose(1, 2),
+                    v.float().view(B, Tk, H, dh).transpose(1, 2), scale, mask).transpose(1, 2).reshape(B * Tq, D)
+    out = E.attention(q.to(DEV).view(B * Tq, D), k.to(DEV).view(B * Tk, D), v.to(DEV).view(B * Tk, D), B, H, Tq, Tk, dh,
+                      D, D, D, scale, key_mask=None if mask is None else mask.to(DEV)).cpu()
+    tol = 2e-2 if dtype == "bf16" else 2e-5
+    torch.testing.assert_close(out.float().double(), ref, atol=tol, rtol=tol)
+
+
+def test_attention_packed_qkv_layout():
+    # q/k/v interleaved as [token][3][H][dh] exactly like the ViT qkv GEMM output (eva_vit.py:125)
+    B, H, T, dh = 2, 16, 257, 88
+    D = H * dh
+    qkv = _bf(_rand((B * T, 3 * D), 43))
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ref = _attn_ref(q.float().view(B, T, H, dh).transpose(1, 2), k.float().view(B, T, H, dh).transpose(1, 2),
+                    v.float().view(B, T, H, dh).transpose(1, 2), dh ** -0.5).transpose(1, 2).reshape(B * T, D)
+    d = qkv.to(DEV)
+    out = E.attention(d[:, :D], d[:, D:2 * D], d[:, 2 * D:], B, H, T, T, dh, 3 * D, 3 * D, 3 * D, dh ** -0.5).cpu()
+    torch.testing.assert_close(out.float().double(), ref, atol=2e-2, rtol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_im2row_assemble_embed_l2norm_mask():
+    import ctypes as C
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    B, S, P, kpad = 3, 224, 14, 640
+    img = _rand((B, 3, S, S), 50)
+    rows = torch.empty((B * 256, kpad), dtype=torch.float32, device=DEV)
+    img_d = img.to(DEV)                     # keep device inputs alive: the C ABI only sees raw pointers
+    L.check(lib.sprc_im2row(img_d.data_ptr(), rows.data_ptr(), B, S, P, kpad, L.SPRC_F32, st))
+    ref = torch.nn.functional.unfold(img, kernel_size=P, stride=P).transpose(1, 2).reshape(B * 256, 588)
+    assert torch.equal(rows.cpu()[:, :588], ref) and torch.all(rows.cpu()[:, 588:] == 0)
+    rows16 = torch.empty((B * 256, kpad), dtype=torch.bfloat16, device=DEV)
+    L.check(lib.sprc_im2row(img_d.data_ptr(), rows16.data_ptr(), B, S, P, kpad, L.SPRC_BF16, st))
+    assert torch.equal(rows16.cpu()[:, :588], ref.to(torch.bfloat16))
+
+    D, T = 1408, 257
+    po, cls, pos = _rand((B * 256, D), 51), _rand((D,), 52), _rand((T, D), 53)
+    x = torch.empty((B, T, D), dtype=torch.float32, device=DEV)
+    po_d, cls_d, pos_d = po.to(DEV), cls.to(DEV), pos.to(DEV)
+    L.check(lib.sprc_vit_assemble(po_d.data_ptr(), cls_d.data_ptr(), pos_d.data_ptr(), x.data_ptr(), B, T, D, st))
+    refx = torch.cat([cls.expand(B, 1, D), po.view(B, 256, D)], dim=1) + pos
+    assert torch.equal(x.cpu(), refx)
+
+    Hd, Lq, Lt, V = 768, 32, 32, 500
+    qe, we, pe = _rand((B, Lq, Hd), 54), _rand((V, Hd), 55), _rand((512, Hd), 56)
+    g, bt = _rand((Hd,), 57) * 0.1 + 1, _rand((Hd,), 58) * 0.1
+    ids = torch.randint(0, V, (B, Lt), generator=torch.Generator().manual_seed(59))
+    y32 = torch.empty((B, Lq + Lt, Hd), dtype=torch.float32, device=DEV)
+    y16 = torch.empty((B, Lq + Lt, Hd), dtype=torch.bfloat16, device=DEV)
+    a = L.QformerEmbedArgs()
+    dv = [t.to(DEV) for t in (qe, ids, we, pe, g, bt)]
+    a.B, a.Lq, a.Lt, a.hidden, a.out_dtype = B, Lq, Lt, Hd, L.SPRC_BF16
+    a.query_embeds, a.q_bstride, a.input_ids, a.word_emb, a.pos_emb = dv[0].data_ptr(), Lq * Hd, dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr()
+    a.gamma, a.beta, a.eps, a.y32, a.y16 = dv[4].data_ptr(), dv[5].data_ptr(), 1e-12, y32.data_ptr(), y16.data_ptr()
+    L.check(lib.sprc_qformer_embed(C.byref(a), st))
+    emb = torch.cat([qe, we[ids] + pe[:Lt]], dim=1)
+    refe = torch.nn.functional.layer_norm(emb, (Hd,), g, bt, 1e-12)
+    torch.testing.assert_close(y32.cpu(), refe, atol=1e-5, rtol=1e-5)
+    assert torch.equal(y16.cpu(), y32.cpu().to(torch.bfloat16))
+    # broadcast query tokens, no text (image-only call shape)
+    a.Lt, a.q_bstride, a.input_ids = 0, 0, None
+    L.check(lib.sprc_qformer_embed(C.byref(a), st))
+    refq = torch.nn.functional.layer_norm(qe[0], (Hd,), g, bt, 1e-12)
+    torch.testing.assert_close(y32.cpu().view(-1, Hd)[:B * Lq].view(B, Lq, Hd), refq.expand(B, -1, -1), atol=1e-5, rtol=1e-5)
+
+    xr = _rand((70, 256), 60, 3.0)
+    xr[5] = 0                                   # zero row: F.normalize's eps clamp
+    o32 = torch.empty_like(xr, device=DEV)
+    o16 = torch.empty((70, 256), dtype=torch.bfloat16, device=DEV)
+    xr_d = xr.to(DEV)
+    L.check(lib.sprc_l2norm_rows(xr_d.data_ptr(), 256, o32.data_ptr(), o16.data_ptr(), 256, 70, 256, L.SPRC_BF16, st))
+    torch.testing.assert_close(o32.cpu(), torch.nn.functional.normalize(xr, dim=-1), atol=1e-6, rtol=1e-6)
+    assert torch.equal(o16.cpu(), o32.cpu().to(torch.bfloat16))
+
+    m = (torch.rand((B, Lt), generator=torch.Generator().manual_seed(61)) > 0.4).long()
+    om = torch.empty((B, Lq + Lt), dtype=torch.float32, device=DEV)
+    m_d = m.to(DEV)
+    L.check(lib.sprc_qformer_mask(m_d.data_ptr(), om.data_ptr(), B, Lq, Lt, st))
+    refm = (1.0 - torch.cat([torch.ones(B, Lq), m.float()], dim=1)) * -10000.0
+    assert torch.equal(om.cpu(), refm)
+
+
+def test_cast_matches_torch_rne():
+    lib = L.load()
+    x = torch.cat([_rand((100003,), 70, 5.0), torch.tensor([0.0, -0.0, 1.0, 65504.0, 1e-40, float("inf"), -float("inf")])])
+    d = x.to(DEV)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=DEV)
+    L.check(lib.sprc_cast_f32_to_bf16(d.data_ptr(), out.data_ptr(), x.numel(), torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(out.cpu().view(torch.int16), x.to(torch.bfloat16).view(torch.int16))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nq,N,k,ties", [(7, 50, 10, False), (33, 2297, 51, False), (9, 64, 64, True), (5, 40, 64, True),
+                                         (16, 1000, 50, True), (3, 1, 5, False), (4, 20000, 64, True)])
+def test_topk_and_rank_of_are_bit_exact(nq, N, k, ties):
+    from oracle import sprc_oracle as O
+    rng = np.random.default_rng(nq * 1000 + N)
+    sim = rng.uniform(-0.3, 1.0, (nq, N)).astype(np.float32)
+    if ties:
+        sim = (np.round(sim * 32) / 32).astype(np.float32)
+    want_sim, want_idx = O.topk_stable(sim, min(k, N))
+    d = torch.from_numpy(sim).to(DEV)
+    vals, idx = E.topk(d, k)
+    vals, idx = vals.cpu().numpy(), idx.cpu().numpy()
+    kk = min(k, N)
+    np.testing.assert_array_equal(idx[:, :kk], want_idx.astype(np.int32))
+    np.testing.assert_array_equal(vals[:, :kk], want_sim)
+    assert np.all(idx[:, kk:] == -1)
+    listed = rng.integers(-1, N, (nq, 8)).astype(np.int32)
+    r = E.rank_of(d, torch.from_numpy(listed)).cpu().numpy()
+    np.testing.assert_array_equal(r, O.rank_of(sim, listed))
+    # global-index variant (what the sharded merge uses): keys tie-break on gidx, not on position
+    perm = np.stack([rng.permutation(N) for _ in range(nq)]).astype(np.int32)
+    _, idx2 = E.topk(torch.from_numpy(np.take_along_axis(sim, perm, axis=1)).to(DEV), k, gidx=torch.from_numpy(perm).to(DEV))
+    np.testing.assert_array_equal(idx2.cpu().numpy()[:, :kk], want_idx.astype(np.int32))
