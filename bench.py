@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SPRC retrieval hot path on MI355X.
+
+metric  : gallery images encoded+ranked / s   (BASELINE.json)
+workload: BASELINE.json configs[1] -- "CIRR-val full gallery (~2k), ViT-g bf16, 1xMI355X, batch 128":
+          a 2297-image gallery and 4181 composed queries (CIRR-val sizes).
+step    : one pass of the hot path over one batch of synthetic input =
+            encode 128 gallery images   (ViT-g/14, 39 blocks -> ln_vision -> Q-Former -> vision_proj -> L2 norm),
+            fuse   232 composed queries (128 * 4181/2297: Q-Former pass 1 + pass 2 -> text_proj -> L2 norm),
+            rank   them against the FULL resident 2297-image gallery (max-over-32 cosine similarity, top-51).
+          value = images processed by all ranks / wall time; inputs are resident in HBM before the timed region.
+N > 1   : weak scaling, one rank per GPU: every rank owns a 2297-image gallery shard and its own queries; the only
+          exchanges are the all_gather of fused query vectors and of per-shard top-k (sprc_amd/dist.py).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = bf16 MFMA GEMM, measured live with HIP events
+on the launch stream inside the timed region) and `cpu_baseline` (the fp32 CPU oracle on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GALLERY, QUERIES, BATCH, TOPK = 2297, 4181, 128, 51
+Q_PER_STEP = (BATCH * QUERIES + GALLERY - 1) // GALLERY          # 233 -> keep CIRR-val's query:image ratio
+MFMA_BF16_PEAK_TFLOPS = 2500.0                                    # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backbone", default="pretrain", choices=["pretrain", "pretrain_vitL"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=4)
+    return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota and at 64 threads
+    (torch's intra-op scaling on 257x1408 GEMMs is flat or negative beyond that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg, n_img: int):
+    """The fp32 CPU oracle (a port of the reference's CPU path; oracle/sprc_oracle.py) on a bounded sample of the
+    same workload: encode n_img images, fuse 2*n_img queries, rank them; all host cores."""
+    from oracle import sprc_oracle as O
+    from sprc_amd import synth
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    sd = synth.make_state_dict(cfg, seed=0)
+    images = synth.make_images(n_img, seed=0)
+    nq = 2 * n_img
+    ids, mask, ref = synth.make_queries(nq, n_img, seed=1)
+    with torch.no_grad():
+        O.extract_target_features(sd, cfg, images[:1])             # warm-up (thread pools, page-in)
+        t0 = time.perf_counter()
+        feats, raw = O.extract_target_features(sd, cfg, images)
+        t1 = time.perf_counter()
+        sim = O.inference(sd, cfg, raw[ref], feats, ids, mask)
+        O.topk_stable(sim.numpy(), min(TOPK, n_img))
+        t2 = time.perf_counter()
+    # scale the query side to the workload's ratio (QUERIES/GALLERY queries per image)
+    per_img = (t1 - t0) / n_img + (t2 - t1) / nq * (QUERIES / GALLERY)
+    return {"value": round(1.0 / per_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 (torch CPU, {cores} threads): encode {n_img} images {t1 - t0:.1f}s + fuse/rank {nq} queries "
+                      f"{t2 - t1:.1f}s, query cost scaled to {QUERIES}/{GALLERY} queries per image"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from sprc_amd import _lib as L
+    from sprc_amd import engine as E
+    from sprc_amd import synth
+    from sprc_amd.config import get_config
+    from sprc_amd.dist import ShardedRanker
+
+    lib = L.load()
+    cfg = get_config(a.backbone)
+    sd = synth.make_state_dict(cfg, seed=0, device=str(dev))      # random-init weights of the named architecture
+    eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=max(BATCH, Q_PER_STEP))
+    del sd
+    torch.cuda.empty_cache()
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn((BATCH, 3, 224, 224), generator=g, device=dev)           # synthetic, already "normalised"
+    ids, mask, _ = synth.make_queries(Q_PER_STEP, GALLERY, seed=1 + rank)
+    ids, mask = ids.to(dev), mask.to(dev)
+    ref_slot = (7919 * torch.arange(Q_PER_STEP, device=dev)) % BATCH             # references come from the batch's raw embeds
+    gallery = torch.nn.functional.normalize(torch.randn((GALLERY, 32, cfg.embed_dim), generator=g, device=dev), dim=-1)
+    ranker = ShardedRanker(gallery, index_base=rank * GALLERY)
+    raw = torch.empty((BATCH, cfg.vit.tokens, cfg.vit.width), dtype=torch.float32, device=dev)
+
+    def step(i: int):
+        eng.vit_forward(images, out=raw)                                          # R3/R4
+        feats, _ = eng.qformer_image(raw)                                         # R5(i) + vision_proj
+        lo = (i * BATCH) % (GALLERY - BATCH)
+        gallery[lo:lo + BATCH].copy_(feats)                                       # resident gallery slice of this batch
+        fusion, _ = eng.qformer_fuse(raw.index_select(0, ref_slot), ids, mask)    # R6 fusion half
+        return ranker.rank(fusion, TOPK)                                          # R6 similarity + R7 top-k (+ exchanges)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    lib.sprc_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = (L.ProfEntry * len(L.K_CLASSES))()
+    L.check(lib.sprc_prof_collect(prof), "sprc_prof_collect")
+    lib.sprc_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        value = world * BATCH * a.steps / dt
+        kidx = 0 if a.dtype == "bf16" else 1
+        pe = prof[kidx]
+        ach = pe.flops / (pe.ms * 1e-3) / 1e12 if pe.ms > 0 else 0.0
+        peak = MFMA_BF16_PEAK_TFLOPS if a.dtype == "bf16" else 157.3
+        kernels = {n: {"ms_per_step": round(prof[j].ms / a.steps, 3), "launches_per_step": prof[j].launches // max(a.steps, 1),
+                       "tflops": round(prof[j].flops / max(prof[j].ms, 1e-9) / 1e9, 1),
+                       "alg_GBs": round(prof[j].bytes / max(prof[j].ms, 1e-9) / 1e6, 1)}
+                   for j, n in enumerate(L.K_CLASSES) if prof[j].launches}
+        out = {
+            "metric": "gallery images encoded+ranked/sec", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"CIRR-val sizes: {GALLERY}-image gallery x {QUERIES} queries, "
+                                   f"{'ViT-g' if a.backbone == 'pretrain' else 'ViT-L'} {a.dtype}, batch {BATCH}; step = encode {BATCH} images + "
+                                   f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
+                       "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
+                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "sprc::gemm_kernel<%s>" % a.dtype, "achieved": round(ach, 1), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                         "launches": int(pe.launches), "avg_launch_ms": round(pe.ms / max(pe.launches, 1), 4),
+                         "alg_flops_per_launch": round(pe.flops / max(pe.launches, 1), 1)},
+            "kernels": kernels,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_images)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,14 @@ typedef struct { int32_t rows_per_group, group_stride, group_offset; } sprc_rowm
 int         sprc_version(void);
 const char* sprc_last_error(void);
 
+/* Per-kernel-class timing with HIP events recorded on the launch stream around every kernel launch
+ * (what bench.py's `roofline` leg reads).  enable(1) clears the records; collect() synchronises the
+ * recorded events and sums elapsed time, ALGORITHMIC flops and bytes per class. */
+enum { SPRC_K_GEMM_BF16 = 0, SPRC_K_GEMM_F32 = 1, SPRC_K_ATTN = 2, SPRC_K_ROWOPS = 3, SPRC_K_RANK = 4, SPRC_K_COUNT = 5 };
+typedef struct { double ms, flops, bytes; int64_t launches; } sprc_prof_entry;
+int sprc_prof_enable(int on);
+int sprc_prof_collect(sprc_prof_entry* out /* [SPRC_K_COUNT] */);
+
 /* fp32 -> bf16 (round-to-nearest-even) weight/feature packing. */
 int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s);
 
@@ -57,8 +65,8 @@ int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream
  * align_prompt.py:348,385.  A and W are `dtype`; bias/resid fp32; out is `out_dtype`.
  * K % 64 == 0 (bf16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (bf16) / 4 (f32) elements.
  *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
- * max32 != 0: "similarity" epilogue -- rows of A are gallery tokens (32 per image), rows of W are
- * query vectors; out[n*ldc + m/32] = max over the 32 rows of image m/32 (align_prompt.py:353-358). */
+ * max32 != 0: "similarity" epilogue -- rows of A are query vectors, rows of W are gallery tokens (32 per
+ * image); out[m*ldc + n/32] = max over the 32 W-rows of image n/32 (align_prompt.py:353-358). */
 typedef struct {
     int32_t M, N, K;
     int32_t dtype, out_dtype, act, max32;

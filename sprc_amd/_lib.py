@@ -45,6 +45,13 @@ class QformerEmbedArgs(C.Structure):
                 ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("y16", vp)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", i64)]
+
+
+K_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "rowops", "rank")
+
+
 class Linear(C.Structure):
     _fields_ = [("w", vp), ("b", vp)]
 
@@ -82,6 +89,8 @@ class QformerModel(C.Structure):
 SIGNATURES = {
     "sprc_version": (i32, []),
     "sprc_last_error": (C.c_char_p, []),
+    "sprc_prof_enable": (i32, [i32]),
+    "sprc_prof_collect": (i32, [C.POINTER(ProfEntry)]),
     "sprc_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
     "sprc_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "sprc_layernorm": (i32, [C.POINTER(LayerNormArgs), vp]),

@@ -268,6 +268,9 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
     AttnParams p{a->B, a->H, a->Tq, a->Tk, a->head_dim, (const char*)a->q, a->ldq, (const char*)a->k, a->ldk,
                  (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale};
     hipStream_t st = (hipStream_t)s;
+    const double bh = (double)a->B * a->H, esz = a->dtype == SPRC_BF16 ? 2.0 : 4.0;
+    ProfScope prof(SPRC_K_ATTN, st, 4.0 * bh * a->Tq * (double)a->Tk * a->head_dim,
+                   bh * a->head_dim * esz * (2.0 * a->Tq + 2.0 * a->Tk));
     if (a->dtype == SPRC_BF16) {
         SPRC_REQUIRE(a->head_dim % 8 == 0 && a->head_dim <= 96, "sprc_attention(bf16): head_dim=%d unsupported", a->head_dim);
         SPRC_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0,

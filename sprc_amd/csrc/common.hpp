@@ -27,6 +27,14 @@ void set_error(const char* fmt, ...);
         }                                                                           \
     } while (0)
 
+// ---- optional per-launch event timing (core.hip) ---------------------------------------------------
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    ProfScope(int cls, hipStream_t stream, double flops, double bytes);
+    ~ProfScope();
+};
+
 // ---- types -----------------------------------------------------------------------------------
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -1,6 +1,9 @@
 // core.hip -- version, error reporting
 #include <stdarg.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.hpp"
 
 namespace sprc {
@@ -11,7 +14,58 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- profiler: event pairs recorded on the launch stream ------------------------------------------
+struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static std::mutex g_prof_mu;
+
+static hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(int cls, hipStream_t stream, double flops, double bytes) : slot(-1), st(stream) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{cls, take_event(), take_event(), flops, bytes};
+    (void)hipEventRecord(r.a, st);
+    slot = (int)g_recs.size();
+    g_recs.push_back(r);
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_recs[slot].b, st);
+}
 }  // namespace sprc
+
+extern "C" int sprc_prof_enable(int on) {
+    using namespace sprc;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    g_prof_on = on != 0;
+    return SPRC_OK;
+}
+
+extern "C" int sprc_prof_collect(sprc_prof_entry* out) {
+    using namespace sprc;
+    SPRC_REQUIRE(out != nullptr, "sprc_prof_collect: null output");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < SPRC_K_COUNT; ++i) out[i] = sprc_prof_entry{0.0, 0.0, 0.0, 0};
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) { set_error("sprc_prof_collect: event sync failed"); return SPRC_ELAUNCH; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes; out[r.cls].launches += 1;
+    }
+    return SPRC_OK;
+}
 
 extern "C" int sprc_version(void) { return SPRC_ABI_VERSION; }
 extern "C" const char* sprc_last_error(void) { return sprc::g_err; }

@@ -169,6 +169,7 @@ extern "C" int sprc_topk(const float* sim, int64_t ld, const int32_t* gidx, int3
     SPRC_REQUIRE(sim && out_sim && out_idx, "sprc_topk: null pointer");
     SPRC_REQUIRE(nq > 0 && N > 0 && ld >= N, "sprc_topk: bad shape nq=%d N=%d ld=%lld", nq, N, (long long)ld);
     SPRC_REQUIRE(k >= 1 && k <= 64, "sprc_topk: k=%d must be in [1,64]", k);
+    ProfScope prof(SPRC_K_RANK, (hipStream_t)s, 0.0, (double)nq * N * (gidx ? 8.0 : 4.0) + (double)nq * k * 8.0);
     hipLaunchKernelGGL(topk_kernel, dim3(nq), dim3(256), 0, (hipStream_t)s, sim, ld, gidx, idx_base, N, k, out_sim, out_idx);
     SPRC_CHECK_LAUNCH("sprc_topk");
     return SPRC_OK;
@@ -178,6 +179,7 @@ extern "C" int sprc_rank_of(const float* sim, int64_t ld, const int32_t* listed,
                             int32_t* rank, sprc_stream s) {
     SPRC_REQUIRE(sim && listed && rank, "sprc_rank_of: null pointer");
     SPRC_REQUIRE(nq > 0 && N > 0 && L > 0 && ld >= N, "sprc_rank_of: bad shape");
+    ProfScope prof(SPRC_K_RANK, (hipStream_t)s, 0.0, (double)nq * N * 4.0);
     hipLaunchKernelGGL(rank_of_kernel, dim3(nq), dim3(256), 0, (hipStream_t)s, sim, ld, listed, N, L, rank);
     SPRC_CHECK_LAUNCH("sprc_rank_of");
     return SPRC_OK;

@@ -225,6 +225,8 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
     SPRC_REQUIRE(a->y32 || a->y16, "sprc_layernorm: no output");
     LnParams p{a->M, a->D, a->x, a->ldx, a->xmap, a->gamma, a->beta, a->eps, a->y32, a->ld32, a->ymap, a->y16, a->ld16};
     const dim3 grid((a->M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
+    ProfScope prof(SPRC_K_ROWOPS, (hipStream_t)s, 8.0 * a->M * (double)a->D,
+                   (double)a->M * a->D * (4.0 + (a->y32 ? 4.0 : 0.0) + (a->y16 ? (double)dtype_size(a->out_dtype) : 0.0)));
     if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, (hipStream_t)s, p);
     SPRC_CHECK_LAUNCH("sprc_layernorm");

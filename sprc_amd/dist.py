@@ -1,0 +1,89 @@
+"""Gallery-sharded retrieval across the GPUs of one node.
+
+The reference is single-process (src/utils.py:14-17); this is new design.  One process per GPU,
+`torch.distributed` with backend "nccl" (= RCCL over xGMI).  Gallery images are independent units:
+rank r encodes and keeps the contiguous slice [r*n_local, (r+1)*n_local) resident; a composed
+query is fused on the rank that owns its reference image (its raw embeds, 1.45 MB, never move).
+The only exchange steps are
+  1. all_gather of the fused query vectors  [nq_local, 256] fp32   (nq*1 KiB in total),
+  2. all_gather of per-shard top-k          [nq, k] (fp32 score, int32 global index) = nq*k*8 B / rank,
+followed by a k*R-candidate merge on every rank.  Both payloads are tiny (latency-bound); no
+all-reduce, no ring over the feature tensors.  Because every comparison uses the integer key
+(fl32(1 - sim), global index), the merged result is bit-identical to the single-GPU ranking.
+
+The compute callables are injected so the orchestration can be exercised with world_size-2 gloo
+tests on CPU (tests/test_dist_cpu.py passes oracle-backed functions); the product default is the
+HIP engine and raises without it.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+SimFn = Callable[[torch.Tensor, torch.Tensor], torch.Tensor]                       # (fusion[nq,E], feats[n,32,E]) -> sim[nq,n]
+TopkFn = Callable[[torch.Tensor, int, Optional[torch.Tensor], int], Tuple[torch.Tensor, torch.Tensor]]
+
+
+def _hip_sim(fusion, feats):
+    from . import engine as E
+    return E.sim_max(fusion.contiguous(), feats.contiguous())
+
+
+def _hip_topk(sim, k, gidx, idx_base):
+    from . import engine as E
+    return E.topk(sim, k, gidx=gidx, idx_base=idx_base)
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced gallery slices; the first (n_total % world) ranks hold one extra image."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def owner_of(index: torch.Tensor, n_total: int, world: int) -> torch.Tensor:
+    """Rank that owns each global gallery index under `shard_bounds`."""
+    base, rem = divmod(n_total, world)
+    big = rem * (base + 1)
+    idx = index.to(torch.int64)
+    small_owner = rem + (idx - big) // max(base, 1)
+    return torch.where(idx < big, idx // (base + 1), small_owner).to(torch.int64)
+
+
+def _all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
+    """all_gather of equally-shaped tensors along dim 0 (one collective)."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world * x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group) if x.is_cuda else \
+        dist.all_gather(list(out.chunk(world, dim=0)), x.contiguous(), group=group)
+    return out
+
+
+class ShardedRanker:
+    """Ranks queries against a gallery sharded over the ranks of `group`."""
+
+    def __init__(self, local_feats: torch.Tensor, index_base: int, sim_fn: SimFn = _hip_sim, topk_fn: TopkFn = _hip_topk,
+                 group=None):
+        self.feats, self.base, self.sim_fn, self.topk_fn, self.group = local_feats, int(index_base), sim_fn, topk_fn, group
+
+    def rank(self, fusion_local: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """fusion_local [nq_local,E] (same nq_local on every rank; pad with zero rows if ragged) ->
+        (sim[nq,k], global idx[nq,k]) for ALL nq = world*nq_local queries, identical on every rank."""
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        fusion = _all_gather_rows(fusion_local, self.group) if world > 1 else fusion_local     # exchange 1
+        sim = self.sim_fn(fusion, self.feats)
+        vals, idx = self.topk_fn(sim, k, None, self.base)
+        if world == 1:
+            return vals, idx
+        nq = fusion.shape[0]
+        cv = _all_gather_rows(vals.t().contiguous(), self.group)                                # exchange 2: [world*k, nq]
+        ci = _all_gather_rows(idx.t().contiguous(), self.group)
+        cand_v = cv.view(world, k, nq).permute(2, 0, 1).reshape(nq, world * k).contiguous()
+        cand_i = ci.view(world, k, nq).permute(2, 0, 1).reshape(nq, world * k).contiguous()
+        # unused slots (shard smaller than k) carry sim=-inf / idx=-1: give them the worst possible key
+        cand_i = torch.where(cand_i < 0, torch.full_like(cand_i, 2**31 - 1), cand_i)
+        mv, mi = self.topk_fn(cand_v, k, cand_i, 0)
+        mi = torch.where(torch.isinf(mv) & (mv < 0), torch.full_like(mi, -1), mi)
+        return mv, mi
