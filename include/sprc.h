@@ -120,7 +120,7 @@ int sprc_vit_assemble(const float* patch_out, const float* cls, const float* pos
  * broadcast), rows [Lq,Lq+Lt) = word_emb[ids] + pos_emb[0..Lt); one LayerNorm over all rows.
  * input_ids may be NULL (Lt = 0).  Writes fp32 and compute-dtype copies. */
 typedef struct {
-    int32_t B, Lq, Lt, hidden, out_dtype;
+    int32_t B, Lq, Lt, hidden, out_dtype, vocab;
     const float* query_embeds; int64_t q_bstride;
     const int64_t* input_ids;
     const float* word_emb; const float* pos_emb;
@@ -187,7 +187,7 @@ typedef struct {
 } sprc_qf_layer;
 
 typedef struct {
-    int32_t dtype, hidden, n_layers, heads, head_dim, ffn, num_query, enc_width, embed_dim, max_txt, n_cross;
+    int32_t dtype, hidden, n_layers, heads, head_dim, ffn, num_query, enc_width, embed_dim, max_txt, n_cross, vocab;
     float ln_eps;
     const float *word_emb, *pos_emb, *emb_ln_w, *emb_ln_b;
     const float* query_tokens;                  /* [num_query, hidden] */

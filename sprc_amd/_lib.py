@@ -40,7 +40,7 @@ class AttentionArgs(C.Structure):
 
 
 class QformerEmbedArgs(C.Structure):
-    _fields_ = [("B", i32), ("Lq", i32), ("Lt", i32), ("hidden", i32), ("out_dtype", i32),
+    _fields_ = [("B", i32), ("Lq", i32), ("Lt", i32), ("hidden", i32), ("out_dtype", i32), ("vocab", i32),
                 ("query_embeds", vp), ("q_bstride", i64), ("input_ids", vp), ("word_emb", vp), ("pos_emb", vp),
                 ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("y16", vp)]
 
@@ -80,7 +80,7 @@ class QfLayer(C.Structure):
 class QformerModel(C.Structure):
     _fields_ = [("dtype", i32), ("hidden", i32), ("n_layers", i32), ("heads", i32), ("head_dim", i32), ("ffn", i32),
                 ("num_query", i32), ("enc_width", i32), ("embed_dim", i32), ("max_txt", i32), ("n_cross", i32),
-                ("ln_eps", f32), ("word_emb", vp), ("pos_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
+                ("vocab", i32), ("ln_eps", f32), ("word_emb", vp), ("pos_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
                 ("query_tokens", vp), ("ckv_all", Linear), ("vision_proj", Linear), ("text_proj", Linear),
                 ("layers", C.POINTER(QfLayer))]
 

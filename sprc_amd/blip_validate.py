@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""`python -m sprc_amd.blip_validate --dataset CIRR --blip-model-name blip2_cir_align_prompt --model-path X`
+
+Entry point with the reference's flags and printed JSON keys (src/blip_validate.py:103-155), running the
+retrieval path on the MI355X HIP engine.  Extra flag: --dtype (bf16 | fp32).
+"""
+from __future__ import annotations
+
+import json
+from argparse import ArgumentParser
+from statistics import geometric_mean, harmonic_mean, mean
+
+import torch
+
+from .harness import compute_cirr_val_metrics, compute_fiq_val_metrics, extract_index_blip_features
+from .model import load_model_and_preprocess
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise SystemExit("sprc_amd needs an MI355X: the HIP kernels are the only compute path")
+    return torch.device("cuda")
+
+
+def _load(blip_model_name, backbone, model_path, dtype):
+    device = _device()
+    model, _, txt = load_model_and_preprocess(name=blip_model_name, model_type=backbone, is_eval=False, device=device,
+                                              compute_dtype=dtype)
+    ckpt = torch.load(model_path, map_location=device)
+    msg = model.load_state_dict(ckpt[model.__class__.__name__], strict=False)     # blip_validate.py:107-109
+    print("Missing keys {}".format(msg.missing_keys))
+    return model, txt
+
+
+def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16"):
+    from .data_utils import CIRRDataset, targetpad_transform
+    model, txt = _load(blip_model_name, backbone, blip_model_path, dtype)
+    preprocess = targetpad_transform(1.25, 224)
+    relative_val = CIRRDataset("val", "relative", preprocess)
+    classic_val = CIRRDataset("val", "classic", preprocess)
+    feats, names = extract_index_blip_features(classic_val, model)
+    r = compute_cirr_val_metrics(relative_val, model, feats, names, txt)
+    g1, g2, g3, r1, r5, r10, r50 = r
+    out = {"group_recall_at1": g1, "group_recall_at2": g2, "group_recall_at3": g3, "recall_at1": r1, "recall_at5": r5,
+           "recall_at10": r10, "recall_at50": r50, "mean(R@5+R_s@1)": (g1 + r5) / 2, "arithmetic_mean": mean(r),
+           "harmonic_mean": harmonic_mean(r), "geometric_mean": geometric_mean(r)}
+    print(json.dumps(out, indent=4))
+    return out
+
+
+def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dtype="bf16"):
+    """FashionIQ evaluation (the reference calls this `clip_finetune_fiq`, blip_validate.py:26-98)."""
+    from .data_utils import FashionIQDataset, targetpad_transform
+    model, txt = _load(blip_model_name, backbone, model_path, dtype)
+    model.eval()
+    preprocess = targetpad_transform(1.25, 224)
+    r10s, r50s = [], []
+    for d in val_dress_types:
+        feats, names = extract_index_blip_features(FashionIQDataset("val", [d], "classic", preprocess), model)
+        r10, r50 = compute_fiq_val_metrics(FashionIQDataset("val", [d], "relative", preprocess), model, feats, names, txt)
+        r10s.append(r10)
+        r50s.append(r50)
+        torch.cuda.empty_cache()
+    out = {}
+    for d, a, b in zip(val_dress_types, r10s, r50s):
+        out[f"{d}_recall_at10"], out[f"{d}_recall_at50"] = a, b
+    out.update({"average_recall_at10": mean(r10s), "average_recall_at50": mean(r50s),
+                "average_recall": (mean(r50s) + mean(r10s)) / 2})
+    print(json.dumps(out, indent=4))
+    return out
+
+
+clip_finetune_fiq = blip_validate_fiq      # the reference's (misleading) name
+
+
+def main(argv=None):
+    p = ArgumentParser()
+    p.add_argument("--dataset", type=str, required=True, help="should be either 'CIRR' or 'fashionIQ'")
+    p.add_argument("--blip-model-name", default="blip2_cir_align_prompt", type=str)
+    p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
+    p.add_argument("--model-path", type=str)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    a = p.parse_args(argv)
+    if a.dataset.lower() not in ("fashioniq", "cirr"):
+        raise ValueError("Dataset should be either 'CIRR' or 'FashionIQ")
+    if a.dataset.lower() == "cirr":
+        blip_validate_cirr(a.blip_model_name, a.backbone, a.model_path, a.dtype)
+    else:
+        blip_validate_fiq(["dress", "toptee", "shirt"], a.blip_model_name, a.backbone, a.model_path, a.dtype)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""`python -m sprc_amd.cirr_test_submission --blip-model-name blip2_cir_align_prompt --model-path X`
+
+CIRR test1 submission files with the reference's flags and JSON layout (src/cirr_test_submission.py:16-58,
+203-222).  The --rerank branch needs `inference_rerank`, which blip2_cir_align_prompt does not define.
+"""
+from __future__ import annotations
+
+import json
+from argparse import ArgumentParser
+
+from .blip_validate import _load
+from .harness import extract_index_blip_features, generate_cirr_test_dicts
+
+
+def generate_cirr_test_submissions(file_name: str, blip_model, preprocess, txt_processors, rerank=False):
+    from .data_utils import CIRRDataset, base_path
+    classic = CIRRDataset("test1", "classic", preprocess)
+    feats, names = extract_index_blip_features(classic, blip_model)
+    relative = CIRRDataset("test1", "relative", preprocess)
+    top, sub = generate_cirr_test_dicts(relative, blip_model, feats, names, txt_processors, rerank)
+    submission = {"version": "rc2", "metric": "recall", **top}
+    group_submission = {"version": "rc2", "metric": "recall_subset", **sub}
+    folder = base_path / "submission" / "CIRR"
+    folder.mkdir(exist_ok=True, parents=True)
+    print("Saving CIRR test predictions")
+    with open(folder / f"recall_submission_{file_name}.json", "w+") as f:
+        json.dump(submission, f, sort_keys=True)
+    with open(folder / f"recall_subset_submission_{file_name}.json", "w+") as f:
+        json.dump(group_submission, f, sort_keys=True)
+
+
+def main(argv=None):
+    from .data_utils import targetpad_transform
+    p = ArgumentParser()
+    p.add_argument("--blip-model-name", default="blip2_cir_align_prompt", type=str)
+    p.add_argument("--model-path", type=str)
+    p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
+    p.add_argument("--rerank", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    a = p.parse_args(argv)
+    model, txt = _load(a.blip_model_name, a.backbone, a.model_path, a.dtype)
+    generate_cirr_test_submissions(f"{a.blip_model_name}_2", model, targetpad_transform(1.25, 224), txt, a.rerank)
+
+
+if __name__ == "__main__":
+    main()

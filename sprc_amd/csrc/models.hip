@@ -276,7 +276,7 @@ extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_e
     RUN(sprc_qformer_mask(attention_mask, q.mask, B, Lq, Lt, st));
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
-    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt;
+    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt; e.vocab = m->vocab;
     e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
     e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
     // pass 1: learned query tokens + text, cross-attention to the reference image (align_prompt.py:332-339)

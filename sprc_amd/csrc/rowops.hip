@@ -107,7 +107,8 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc
         load_row(r, p.query_embeds + (int64_t)b * p.q_bstride + (int64_t)t * p.hidden, nch, lane);
     } else {
         const int pos = t - p.Lq;
-        const int64_t id = p.input_ids[(int64_t)b * p.Lt + pos];
+        int64_t id = p.input_ids[(int64_t)b * p.Lt + pos];
+        id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);          // memory safety; the host validates CPU inputs
         RowRegs pe;
         load_row(r, p.word_emb + id * p.hidden, nch, lane);
         load_row(pe, p.pos_emb + (int64_t)pos * p.hidden, nch, lane);

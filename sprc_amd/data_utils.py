@@ -1,0 +1,146 @@
+"""Host-side datasets and preprocessing for the evaluation entry points (image decode is host I/O; SURVEY.md
+section 8(f) N3 keeps GPU preprocessing as a "next" row).
+
+Same on-disk layout, dataset modes and item tuples as the reference's src/data_utils.py (CIRR :203-286,
+FashionIQ :108-200, TargetPad + CLIP normalisation :49-105) so the reference's data directory works as is;
+the root is `SPRC_DATA_ROOT` (default: the parent of this repository, like the reference's `base_path`).
+torchvision is not required: the transform is PIL + torch.
+"""
+from __future__ import annotations
+
+import json
+import os
+from pathlib import Path
+from typing import Callable, List
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+base_path = Path(os.environ.get("SPRC_DATA_ROOT", Path(__file__).resolve().parents[2]))
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class TargetPad:
+    """Zero-pad towards `target_ratio` when the aspect ratio exceeds it (data_utils.py:49-72)."""
+
+    def __init__(self, target_ratio: float, size: int):
+        self.target_ratio, self.size = target_ratio, size
+
+    def __call__(self, image):
+        from PIL import ImageOps
+        w, h = image.size
+        if max(w, h) / min(w, h) < self.target_ratio:
+            return image
+        scaled = max(w, h) / self.target_ratio
+        hp, vp = max(int((scaled - w) / 2), 0), max(int((scaled - h) / 2), 0)
+        return ImageOps.expand(image, border=(hp, vp, hp, vp), fill=0)
+
+
+def targetpad_transform(target_ratio: float, dim: int) -> Callable:
+    """TargetPad -> bicubic resize (short side = dim) -> centre crop -> RGB -> [0,1] CHW -> CLIP normalise
+    (data_utils.py:91-105)."""
+    from PIL import Image
+    pad = TargetPad(target_ratio, dim)
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+
+    def tf(image):
+        image = pad(image)
+        w, h = image.size
+        if w <= h:
+            nw, nh = dim, int(dim * h / w)
+        else:
+            nw, nh = int(dim * w / h), dim
+        image = image.resize((nw, nh), Image.BICUBIC)
+        left, top = int(round((nw - dim) / 2.0)), int(round((nh - dim) / 2.0))
+        image = image.crop((left, top, left + dim, top + dim)).convert("RGB")
+        x = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+        return (x - mean) / std
+
+    return tf
+
+
+class _Base(Dataset):
+    def __getitem__(self, index):
+        try:
+            return self._get(index)
+        except Exception as e:           # the reference swallows per-item errors and yields None (collate_fn drops it)
+            print(f"Exception: {e}")
+            return None
+
+
+class CIRRDataset(_Base):
+    """'classic': (name, image); 'relative': val -> (ref_name, target_name, caption, members),
+    test1 -> (pair_id, ref_name, caption, members)."""
+
+    def __init__(self, split: str, mode: str, preprocess: Callable):
+        if split not in ("test1", "train", "val"):
+            raise ValueError("split should be in ['test1', 'train', 'val']")
+        if mode not in ("relative", "classic"):
+            raise ValueError("mode should be in ['relative', 'classic']")
+        self.split, self.mode, self.preprocess = split, mode, preprocess
+        root = base_path / "cirr_dataset" / "cirr"
+        self.triplets = json.loads((root / "captions" / f"cap.rc2.{split}.json").read_text())
+        self.name_to_relpath = json.loads((root / "image_splits" / f"split.rc2.{split}.json").read_text())
+        self.names = list(self.name_to_relpath.keys())
+        print(f"CIRR {split} dataset in {mode} mode initialized")
+
+    def _image(self, name):
+        from PIL import Image
+        return self.preprocess(Image.open(base_path / "cirr_dataset" / self.name_to_relpath[name]))
+
+    def _get(self, index):
+        if self.mode == "classic":
+            name = self.names[index]
+            return name, self._image(name)
+        t = self.triplets[index]
+        members, ref, cap = t["img_set"]["members"], t["reference"], t["caption"]
+        if self.split == "val":
+            return ref, t["target_hard"], cap, members
+        if self.split == "test1":
+            return t["pairid"], ref, cap, members
+        return self._image(ref), self._image(t["target_hard"]), cap
+
+    def __len__(self):
+        return len(self.triplets) if self.mode == "relative" else len(self.names)
+
+
+class FashionIQDataset(_Base):
+    """'classic': (name, image); 'relative': val -> (ref_name, target_name, [cap1, cap2])."""
+
+    def __init__(self, split: str, dress_types: List[str], mode: str, preprocess: Callable):
+        if mode not in ("relative", "classic"):
+            raise ValueError("mode should be in ['relative', 'classic']")
+        if split not in ("test", "train", "val"):
+            raise ValueError("split should be in ['test', 'train', 'val']")
+        for d in dress_types:
+            if d not in ("dress", "shirt", "toptee"):
+                raise ValueError("dress_type should be in ['dress', 'shirt', 'toptee']")
+        self.split, self.mode, self.dress_types, self.preprocess = split, mode, dress_types, preprocess
+        root = base_path / "fashionIQ_dataset"
+        self.triplets, self.image_names = [], []
+        for d in dress_types:
+            self.triplets += json.loads((root / "captions" / f"cap.{d}.{split}.json").read_text())
+            self.image_names += json.loads((root / "image_splits" / f"split.{d}.{split}.json").read_text())
+        print(f"FashionIQ {split} - {dress_types} dataset in {mode} mode initialized")
+
+    def _image(self, name):
+        from PIL import Image
+        return self.preprocess(Image.open(base_path / "fashionIQ_dataset" / "images" / f"{name}.png"))
+
+    def _get(self, index):
+        if self.mode == "classic":
+            name = self.image_names[index]
+            return name, self._image(name)
+        t = self.triplets[index]
+        if self.split == "val":
+            return t["candidate"], t["target"], t["captions"]
+        if self.split == "test":
+            return t["candidate"], self._image(t["candidate"]), t["captions"]
+        return self._image(t["candidate"]), self._image(t["target"]), t["captions"]
+
+    def __len__(self):
+        return len(self.triplets) if self.mode == "relative" else len(self.image_names)

@@ -241,7 +241,7 @@ class Engine:
         m = L.QformerModel()
         m.dtype, m.hidden, m.n_layers, m.heads, m.head_dim, m.ffn = self.dt, q.hidden, q.layers, q.heads, q.head_dim, q.ffn
         m.num_query, m.enc_width, m.embed_dim, m.max_txt, m.n_cross = q.num_query, self.cfg.vit.width, self.cfg.embed_dim, self.cfg.max_txt_len, n_cross
-        m.ln_eps = q.ln_eps
+        m.ln_eps, m.vocab = q.ln_eps, q.vocab
         m.word_emb = self._f32(sd[p + "embeddings.word_embeddings.weight"]).data_ptr()
         m.pos_emb = self._f32(sd[p + "embeddings.position_embeddings.weight"]).data_ptr()
         m.emb_ln_w, m.emb_ln_b = ln(p + "embeddings.LayerNorm")
@@ -300,8 +300,8 @@ class Engine:
         B, E = ref.shape[0], self.cfg.embed_dim
         if ids.shape != (B, self.cfg.max_txt_len) or mask.shape != ids.shape:
             raise ValueError(f"input_ids/attention_mask must be [{B},{self.cfg.max_txt_len}]")
-        if int(ids.min()) < 0 or int(ids.max()) >= self.cfg.qformer.vocab:
-            raise IndexError("token id out of range")
+        if not input_ids.is_cuda and (int(input_ids.min()) < 0 or int(input_ids.max()) >= self.cfg.qformer.vocab):
+            raise IndexError("token id out of range")       # device-resident ids are clamped by the kernel (no host sync)
         fusion = torch.empty((B, E), dtype=torch.float32, device=self.device)
         f16 = torch.empty((B, E), dtype=self.tdt, device=self.device) if self.dt == L.SPRC_BF16 else None
         for s in range(0, B, self.max_batch):

@@ -201,7 +201,7 @@ def test_im2row_assemble_embed_l2norm_mask():
     y16 = torch.empty((B, Lq + Lt, Hd), dtype=torch.bfloat16, device=DEV)
     a = L.QformerEmbedArgs()
     dv = [t.to(DEV) for t in (qe, ids, we, pe, g, bt)]
-    a.B, a.Lq, a.Lt, a.hidden, a.out_dtype = B, Lq, Lt, Hd, L.SPRC_BF16
+    a.B, a.Lq, a.Lt, a.hidden, a.out_dtype, a.vocab = B, Lq, Lt, Hd, L.SPRC_BF16, V
     a.query_embeds, a.q_bstride, a.input_ids, a.word_emb, a.pos_emb = dv[0].data_ptr(), Lq * Hd, dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr()
     a.gamma, a.beta, a.eps, a.y32, a.y16 = dv[4].data_ptr(), dv[5].data_ptr(), 1e-12, y32.data_ptr(), y16.data_ptr()
     L.check(lib.sprc_qformer_embed(C.byref(a), st))
