@@ -3,23 +3,28 @@
 // Replaces every nn.Linear / F.linear / conv-as-GEMM on the SPRC retrieval path (see sprc.h).
 // Both operands are K-contiguous ("B^T" form), so A and W fragments are read the same way.
 //
-// One kernel template, three tile configurations (workgroup tile BM x BN, K-tile = 128 bytes of K):
-//   256 x 256, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA 32x32 accumulators   (large GEMMs)
-//   256 x 128, 8 waves (4 x 2), wave tile  64 x 64 = 2 x 2                            (N = 1408-class GEMMs)
-//   128 x 128, 4 waves (2 x 2), wave tile  64 x 64 = 2 x 2                            (small GEMMs, 3 WGs / CU)
+// One kernel template, two tile configurations (workgroup tile BM x BN, K-tile = 128 bytes of K):
+//   256 x 256, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA 32x32 accumulators, 1 WG / CU   (large GEMMs)
+//   128 x 128, 4 waves (2 x 2), wave tile  64 x 64 = 2 x 2,                         2 WGs / CU  (small GEMMs)
 //     bf16: v_mfma_f32_32x32x16_bf16, K-tile = 64 elements;  f32: v_mfma_f32_32x32x2_f32 (exact fp32), 32 elements
-// Why big tiles: a CU's vector-memory path delivers ~64 B/clk; a 128x128x64 tile needs 32 KiB per 512
-// MFMA-cycles = 64 B/clk at peak MFMA rate (measured: 517-635 TFLOP/s, memory-path bound), a 256x256 tile
-// needs half of that.
-// Data movement: K-tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction,
-// no VGPR round trip), double buffered, next tile issued before the current tile's MFMAs.  The LDS image of
-// a wave-instruction is lane-linear (8 rows x 8 16-B slots), so the XOR swizzle (slot ^= (row>>1)&7, which
-// makes every ds_read_b128 lane group hit 16 distinct slots of the 256-B bank row) is applied to the
-// per-lane SOURCE address and to the fragment reads, never to the destination (guide rule 21).
-// Fragment reads are software pipelined one MFMA k-step ahead (registers double buffered).
-// Grid: 1-D, XCD-aware remap (block b runs on XCD b%8 -> each XCD gets a contiguous tile range) and an
-// 8-row grouped tile order so concurrently resident tiles share A/W panels in the XCD's L2.
+// Why big tiles: a CU's vector-memory path delivers ~64 B/clk; a 128x128x64 tile needs 32 KiB per 512 MFMA-cycles
+// = 64 B/clk at peak MFMA rate (measured 517-635 TFLOP/s, memory-path bound); a 256x256 tile needs half of that.
+// Data movement: K-tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
+// round trip), double buffered.  The LDS image of a wave-instruction is lane-linear (8 rows x 8 16-B slots), so the
+// XOR swizzle (slot ^= (row>>1)&7: every ds_read_b128 lane group hits 16 distinct slots of the 256-B bank row,
+// SQ_LDS_BANK_CONFLICT = 0) is applied to the per-lane SOURCE address and to the fragment reads, never to the
+// destination (guide rule 21).
+// bf16 main loop is hand software-pipelined (inline-asm ds_read_b128 + counted lgkmcnt): fragment reads of k-step
+// kk+1 and a quarter of the next K-tile's global->LDS loads are issued before the MFMAs of k-step kk.
+// The kernel body is a tile loop (optional persistent mode: grid = CUs x residency, next tile's K-tile 0 prefetched
+// before the epilogue); measured no gain over one workgroup per tile, which is what is launched.
+// Tile order: XCD-contiguous remap of vb (block b runs on XCD b%8) + 8-row grouped order, so tiles resident on one
+// XCD share A/W panels in its L2.
+// Epilogue: MFMAs compute the TRANSPOSED tile, so a lane owns one C row and 4 consecutive columns per register
+// quad: bias / residual / output are 16-B (fp32) or 8-B (bf16) vectors.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -61,160 +66,73 @@ template <> struct Frag<float> { typedef f32x4 type; };
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
-// KT_BYTES: bytes of K per row per K-tile (128 or 64).  STAGES: 1 (single buffer, 2 barriers per tile),
-// 2 (double buffer, __syncthreads) or >= 3 (ring: loads STAGES-1 tiles ahead, counted vmcnt + raw s_barrier so
-// the prefetched tiles stay in flight across the barrier -- guide T3/T4).
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int KT_BYTES, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 64 * WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int STAGE_BYTES = (BM + BN) * KT_BYTES;
-    constexpr int SPR = KT_BYTES / 16, RPB = 256 / KT_BYTES;   // 16-B slots per row; rows per 256-B LDS bank row
-    constexpr int KSTEPS = KT_BYTES / 32;                      // MFMA k-steps per K-tile
-    constexpr int LA = BM * SPR / NT, LB = BN * SPR / NT;      // 16-B chunks per thread per K-tile
-    static_assert(BM * SPR % NT == 0 && BN * SPR % NT == 0, "tile/threads mismatch");
-    typedef typename Frag<T>::type frag_t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WN, wc = wave % WN;
-    const int r32 = lane & 31, half = lane >> 5;
+// ds_read_b128 the compiler cannot sink: issued where written, completion tracked by OUR lgkmcnt (guide 5.7).
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);       // keep the MFMAs below the wait (guide rule 18)
+}
 
-    // ---- tile id: XCD-contiguous remap (bijective for any grid), then grouped (8 m-tiles) order ----
-    const int nwg = p.tiles_m * p.tiles_n;
-    int pid;
+// One K-tile (4 MFMA k-steps) of a wave's TM x TN accumulator block, hand software-pipelined.
+// a_base / b_base: LDS byte address of this lane's first A / W row in the current stage; c0 = swizzled slot of
+// k-step 0 ((half ^ f(row)) << 4); k-step kk reads slot c0 ^ (kk << 5).
+template <int TM, int TN, int KT_BYTES, typename Issue>
+__device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base, uint32_t c0, f32x16 (&acc)[TM][TN],
+                                                Issue&& issue) {
+    static_assert(KT_BYTES == 128, "4 k-steps per K-tile");
+    u32x4 fa[2][TM], fb[2][TN];
     {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        const uint32_t an = a_base + c0, bn = b_base + c0;
+        static_for<0, TM>([&](auto i) { fa[0][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(an); });
+        static_for<0, TN>([&](auto i) { fb[0][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(bn); });
     }
-    constexpr int GROUP_M = 8;
-    const int in_group = GROUP_M * p.tiles_n;
-    const int group_id = pid / in_group;
-    const int first_m = group_id * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int pid_m = first_m + (pid % in_group) % gsz;
-    const int pid_n = (pid % in_group) / gsz;
-    const int m0 = pid_m * BM, n0 = pid_n * BN;
-
-    // ---- direct-to-LDS staging: lane fills physical slot (lane&7) of row (chunk>>3) with logical slot^f(row) ----
-    const char* a_src[LA];
-    const char* w_src[LB];
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int c = i * NT + tid, row = c / SPR, slot = (c % SPR) ^ ((row / RPB) % SPR);
-        const int am = min(m0 + row, p.M - 1);
-        a_src[i] = p.A + map_row_s(p.a_shift, p.a_stride, p.a_off, am) * p.lda_b + slot * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-        const int c = i * NT + tid, row = c / SPR, slot = (c % SPR) ^ ((row / RPB) % SPR);
-        const int wn = min(n0 + row, p.N - 1);
-        w_src[i] = p.W + (int64_t)wn * p.ldw_b + slot * 16;
-    }
-    auto stage = [&](int buf, int64_t ko) {
-        char* dst = smem + buf * STAGE_BYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < LA; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + ko), (lptr_t)(dst + i * NT * 16), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + ko), (lptr_t)(dst + BM * KT_BYTES + i * NT * 16), 16, 0, 0);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    const int sw = (r32 / RPB) % SPR;
-    const int a_off = (wr * TM * 32 + r32) * KT_BYTES, b_off = BM * KT_BYTES + (wc * TN * 32 + r32) * KT_BYTES;
-    auto compute = [&](const char* st) {
-        frag_t fa[2][TM], fb[2][TN];
-        auto load = [&](int buf, int kk) {
-            const int slot = ((kk * 2 + half) ^ sw) << 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[buf][i] = *reinterpret_cast<const frag_t*>(st + a_off + i * 32 * KT_BYTES + slot);
-#pragma unroll
-            for (int i = 0; i < TN; ++i) fb[buf][i] = *reinterpret_cast<const frag_t*>(st + b_off + i * 32 * KT_BYTES + slot);
-        };
-        load(0, 0);
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            if (kk + 1 < KSTEPS) load((kk + 1) & 1, kk + 1);
-            if constexpr (sizeof(T) == 2) {
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk & 1][ni], fa[kk & 1][mi], acc[mi][ni], 0, 0, 0);
-            } else {
-                // each lane holds 4 consecutive k of its half; MFMA step t pairs k = {8kk+t, 8kk+4+t}
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < TN; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kk & 1][ni][t], fa[kk & 1][mi][t], acc[mi][ni], 0, 0, 0);
-            }
+    static_for<0, 4>([&](auto kk_) {
+        constexpr int kk = decltype(kk_)::value, cur = kk & 1, nxt = cur ^ 1;
+        if constexpr (kk < 3) {
+            const uint32_t cn = c0 ^ ((kk + 1) << 5), an = a_base + cn, bn = b_base + cn;
+            static_for<0, TM>([&](auto i) { fa[nxt][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(an); });
+            static_for<0, TN>([&](auto i) { fb[nxt][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(bn); });
         }
-    };
-
-    const int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
-    if constexpr (STAGES == 2) {             // one barrier per K-tile; next tile in flight during the MFMAs
-        stage(0, 0);
-        for (int t = 0; t < nt; ++t) {
-            __syncthreads();                 // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free again
-            if (t + 1 < nt) stage((t + 1) & 1, (int64_t)(t + 1) * KT_BYTES);
-            compute(smem + (t & 1) * STAGE_BYTES);
-        }
-    } else if constexpr (STAGES == 1) {      // one buffer: co-resident workgroups hide each other's load phase
-        for (int t = 0; t < nt; ++t) {
-            stage(0, (int64_t)t * KT_BYTES);
-            __syncthreads();
-            compute(smem);
-            __syncthreads();
-        }
-    } else {                                 // ring of STAGES buffers, STAGES-1 tiles in flight
-        constexpr int LT = LA + LB;          // VMEM ops per thread per K-tile
-        static_assert(STAGES <= 4 && LT * (STAGES - 2) < 64, "vmcnt range");
+        issue(kk_);
+        if constexpr (kk < 3) wait_lgkmcnt<TM + TN>();
+        else wait_lgkmcnt<0>();
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s)
-            if (s < nt) stage(s, (int64_t)s * KT_BYTES);
-        int buf = 0, nbuf = STAGES - 1;
-        for (int t = 0; t < nt; ++t) {
-            const int ahead = min(STAGES - 2, nt - 1 - t);       // tiles allowed to stay in flight behind tile t
-            if (ahead >= 2) wait_vmcnt<2 * LT>();
-            else if (ahead == 1) wait_vmcnt<LT>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();    // tile t landed for every wave; everyone finished reading buffer nbuf
-            asm volatile("" ::: "memory");
-            if (t + STAGES - 1 < nt) stage(nbuf, (int64_t)(t + STAGES - 1) * KT_BYTES);
-            compute(smem + buf * STAGE_BYTES);
-            buf = (buf + 1 == STAGES) ? 0 : buf + 1;
-            nbuf = (nbuf + 1 == STAGES) ? 0 : nbuf + 1;
-        }
-    }
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cur][ni]),
+                                                                      __builtin_bit_cast(bf16x8, fa[cur][mi]), acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    });
+}
 
-    // ---- epilogue.  The MFMAs compute the TRANSPOSED tile (W fragment as the A operand), so the 32x32 D layout
-    // puts the C row on the lane and 4 consecutive C columns in consecutive registers:
-    //   m = rbase + (lane&31),   n = cbase + 8*(r>>2) + 4*(lane>>5) + (r&3)
-    // -> bias / residual / output move as 16-B (fp32) or 8-B (bf16) vectors, one row pointer per lane.
-    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
+// ---- epilogue (shared).  Transposed 32x32 D layout: m = rbase + (lane&31),  n = cbase + 8*(r>>2) + 4*(lane>>5) + (r&3) ----
+template <typename T, typename OutT, int ACT, bool MAX32, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int cm0, int cn0, int wr, int wc,
+                                              int r32, int half, bool vec_ok) {
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
-        const int row = m0 + (wr * TM + mi) * 32 + r32;
+        const int row = cm0 + (wr * TM + mi) * 32 + r32;
         if constexpr (MAX32) {
             // rows m = query vectors, columns n = gallery tokens: max over the 32 columns of one image
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni) {
-                const int cbase = n0 + (wc * TN + ni) * 32;
+                const int cbase = cn0 + (wc * TN + ni) * 32;
                 float v = acc[mi][ni][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[mi][ni][r]);
@@ -234,7 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
                     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const int col = n0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
+                            const int col = cn0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
                             rv[ni][g] = (row_ok && col < p.N) ? *reinterpret_cast<const f32x4*>(rrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
                         }
                 }
@@ -242,7 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int col = n0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
+                        const int col = cn0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
                         if (!(row_ok && col < p.N)) continue;
                         f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
                         if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + col);
@@ -268,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int col = n0 + (wc * TN + ni) * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                        const int col = cn0 + (wc * TN + ni) * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
                         if (!(row_ok && col < p.N)) continue;
                         float v = acc[mi][ni][r] + (p.bias ? p.bias[col] : 0.f);
                         if constexpr (ACT == SPRC_ACT_GELU) {
@@ -285,6 +203,272 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     }
 }
 
+template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, bool PERSIST>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KT_BYTES = 128;
+    constexpr int NT = 64 * WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int STAGE_BYTES = (BM + BN) * KT_BYTES;
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;          // 16-B chunks per thread per K-tile
+    constexpr int LQ = (LA + LB) / 4;                          // global->LDS loads issued per MFMA k-step
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0 && (LA + LB) % 4 == 0, "tile/threads mismatch");
+    typedef typename Frag<T>::type frag_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
+
+    // ---- virtual block id -> tile: XCD-contiguous remap (bijective for any count), then grouped (8 m-tiles) order ----
+    auto tile_of = [&](int vb, int& m0, int& n0) {
+        const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+        constexpr int GROUP_M = 8;
+        const int in_group = GROUP_M * p.tiles_n;
+        const int first_m = (pid / in_group) * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (pid % in_group) % gsz) * BM;
+        n0 = ((pid % in_group) / gsz) * BN;
+    };
+
+    // ---- direct-to-LDS staging: lane fills physical slot (chunk&7) of row (chunk>>3) with logical slot^f(row) ----
+    const char* a_src[LA];
+    const char* w_src[LB];
+    auto setup = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
+            const int am = min(m0 + row, p.M - 1);
+            a_src[i] = p.A + map_row_s(p.a_shift, p.a_stride, p.a_off, am) * p.lda_b + slot * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
+            const int wn = min(n0 + row, p.N - 1);
+            w_src[i] = p.W + (int64_t)wn * p.ldw_b + slot * 16;
+        }
+    };
+    auto stage_one = [&](auto j_, char* dst, int64_t ko) {      // j-th of the LA+LB loads of one K-tile
+        constexpr int j = decltype(j_)::value;
+        if constexpr (j < LA)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + ko), (lptr_t)(dst + j * NT * 16), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j - LA] + ko), (lptr_t)(dst + BM * KT_BYTES + (j - LA) * NT * 16), 16, 0, 0);
+    };
+    auto stage = [&](int buf, int64_t ko) {
+        char* dst = smem + buf * STAGE_BYTES + wave * 1024;
+        static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst, ko); });
+    };
+
+    const int sw = (r32 >> 1) & 7;
+    const int a_off = (wr * TM * 32 + r32) * KT_BYTES, b_off = BM * KT_BYTES + (wc * TN * 32 + r32) * KT_BYTES;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const uint32_t c0 = (uint32_t)((half ^ sw) << 4);
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
+
+    int vb = blockIdx.x, m0, n0;
+    tile_of(vb, m0, n0);
+    setup(m0, n0);
+    stage(0, 0);                                                // K-tile 0 of the first tile
+
+    while (true) {
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+        // ---- main loop: K-tile t is in buffer t&1 (tile 0 was issued before we got here) ----
+        for (int t = 0; t < nt; ++t) {
+            __syncthreads();                 // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free again
+            const bool more = t + 1 < nt;
+            const int64_t ko = (int64_t)(t + 1) * KT_BYTES;
+            if constexpr (sizeof(T) == 2) {
+                char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
+                const uint32_t so = lds0 + (t & 1) * STAGE_BYTES;
+                pipe_ktile_bf16<TM, TN, KT_BYTES>(so + a_off, so + b_off, c0, acc, [&](auto kk_) {
+                    constexpr int kk = decltype(kk_)::value;
+                    if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
+                });
+            } else {
+                if (more) stage((t + 1) & 1, ko);
+                const char* st = smem + (t & 1) * STAGE_BYTES;
+                frag_t fa[2][TM], fb[2][TN];
+                auto load = [&](int buf, int kk) {
+                    const int slot = ((kk * 2 + half) ^ sw) << 4;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[buf][i] = *reinterpret_cast<const frag_t*>(st + a_off + i * 32 * KT_BYTES + slot);
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) fb[buf][i] = *reinterpret_cast<const frag_t*>(st + b_off + i * 32 * KT_BYTES + slot);
+                };
+                load(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kk + 1 < 4) load((kk + 1) & 1, kk + 1);
+                    // each lane holds 4 consecutive k of its half; MFMA step e pairs k = {8kk+e, 8kk+4+e}
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < TN; ++ni)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kk & 1][ni][e], fa[kk & 1][mi][e], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- hand over: prefetch the next tile's K-tile 0, then write this tile out ----
+        const int cm0 = m0, cn0 = n0;
+        const int vb_next = vb + gridDim.x;
+        const bool has_next = PERSIST && vb_next < nwg;
+        __syncthreads();                     // every wave is done reading LDS
+        if (has_next) {
+            tile_of(vb_next, m0, n0);
+            setup(m0, n0);
+            stage(0, 0);
+        }
+
+        gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, cm0, cn0, wr, wc, r32, half, vec_ok);
+        if (!has_next) break;
+        vb = vb_next;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Continuous-pipeline bf16 variant.  K is consumed in UNITS of 32 elements (64-byte rows = 2 MFMA k-steps); LDS holds a
+// ring of 4 units.  The workgroup barrier does NOT sit at a unit boundary (where every wave would then stall on LDS
+// latency with an empty fragment pipeline) but in the MIDDLE of each unit, between its two k-steps:
+//     k-step 0 of unit u:  issue fragment reads (u, k1)      | wait lgkmcnt | 8 MFMAs (u, k0)
+//     hand-over:           s_waitcnt vmcnt (own loads of unit u+1 landed) ; s_barrier ; issue loads of unit u+3
+//     k-step 1 of unit u:  issue fragment reads (u+1, k0)    | wait lgkmcnt | 8 MFMAs (u, k1)
+// After barrier u every wave's part of unit u+1 has landed (RAW) and every wave has finished reading unit u-1, whose
+// buffer receives unit u+3 (WAR).  Global->LDS loads therefore fly 2.5 units (~2500 MFMA cycles) ahead with COUNTED
+// vmcnt waits, and the fragment software pipeline never drains between units (guide T3/T4 applied to this tiling).
+// LDS rows are 64 B: slot swizzle f(row) = (row>>2)&3 keeps ds_read_b128 conflict-free (4 rows per 256-B bank row).
+template <typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef bf16_t T;
+    constexpr int UB = 64, RING = 4;
+    constexpr int NT = 64 * WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int UNIT_BYTES = (BM + BN) * UB;
+    constexpr int LA = BM * 4 / NT, LB = BN * 4 / NT, LU = LA + LB;    // 16-B chunks per thread per unit
+    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile/threads mismatch");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WN, wc = wave % WN;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int nu = p.K / 32;
+
+    int m0, n0;
+    {
+        const int vb = blockIdx.x, xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+        constexpr int GROUP_M = 8;
+        const int in_group = GROUP_M * p.tiles_n;
+        const int first_m = (pid / in_group) * GROUP_M;
+        const int gsz = min(p.tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (pid % in_group) % gsz) * BM;
+        n0 = ((pid % in_group) / gsz) * BN;
+    }
+    const char* a_src[LA];
+    const char* w_src[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int c = i * NT + tid, row = c >> 2, slot = (c & 3) ^ ((row >> 2) & 3);
+        const int am = min(m0 + row, p.M - 1);
+        a_src[i] = p.A + map_row_s(p.a_shift, p.a_stride, p.a_off, am) * p.lda_b + slot * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const int c = i * NT + tid, row = c >> 2, slot = (c & 3) ^ ((row >> 2) & 3);
+        const int wn = min(n0 + row, p.N - 1);
+        w_src[i] = p.W + (int64_t)wn * p.ldw_b + slot * 16;
+    }
+    auto issue_unit = [&](int u) {
+        char* dst = smem + (u & (RING - 1)) * UNIT_BYTES + wave * 1024;
+        const int64_t ko = (int64_t)u * UB;
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + ko), (lptr_t)(dst + i * NT * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + ko), (lptr_t)(dst + BM * UB + i * NT * 16), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const uint32_t c0 = (uint32_t)((half ^ ((r32 >> 2) & 3)) << 4);
+    const uint32_t a_off = lds0 + (wr * TM * 32 + r32) * UB, b_off = lds0 + BM * UB + (wc * TN * 32 + r32) * UB;
+    u32x4 fa[2][TM], fb[2][TN];
+    auto reads = [&](auto buf_, int u, int kk) {                  // fragments of (unit u, k-step kk) -> fa/fb[buf]
+        constexpr int buf = decltype(buf_)::value;
+        const uint32_t o = (u & (RING - 1)) * UNIT_BYTES + (c0 ^ (kk << 5));
+        const uint32_t an = a_off + o, bn = b_off + o;
+        static_for<0, TM>([&](auto i) { fa[buf][i] = lds_read128<decltype(i)::value * 32 * UB>(an); });
+        static_for<0, TN>([&](auto i) { fb[buf][i] = lds_read128<decltype(i)::value * 32 * UB>(bn); });
+    };
+    auto mfmas = [&](auto buf_) {
+        constexpr int buf = decltype(buf_)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[buf][ni]),
+                                                                      __builtin_bit_cast(bf16x8, fa[buf][mi]), acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // prologue: units 0..2 in flight, unit 0 landed for everyone, first fragments requested
+    issue_unit(0);
+    if (nu > 1) issue_unit(1);
+    if (nu > 2) issue_unit(2);
+    if (nu > 2) wait_vmcnt<2 * LU>();
+    else if (nu > 1) wait_vmcnt<LU>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    reads(I0{}, 0, 0);
+
+    for (int u = 0; u < nu; ++u) {
+        reads(I1{}, u, 1);
+        wait_lgkmcnt<TM + TN>();
+        mfmas(I0{});
+        // hand-over (see header)
+        if (u + 2 < nu) wait_vmcnt<LU>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (u + 3 < nu) issue_unit(u + 3);
+        if (u + 1 < nu) {
+            reads(I0{}, u + 1, 0);
+            wait_lgkmcnt<TM + TN>();
+        } else {
+            wait_lgkmcnt<0>();
+        }
+        mfmas(I1{});
+    }
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
+    gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
+}
+
 static int ilog2_exact(int v) {
     if (v <= 0) return -1;
     int s = 0;
@@ -292,26 +476,48 @@ static int ilog2_exact(int v) {
     return ((1 << s) == v) ? s : -2;
 }
 
-// SPRC_GEMM_TILE: 0 = automatic (default), 1 = 128x128 single buffer, 2 = 128x128 double buffer,
-//                 3 = 256x128 double buffer, 4 = 256x256 double buffer, 5 = 256x256 K64-byte tiles 4-stage ring,
-//                 6 = 256x128 3-stage ring, 7 = 128x128 4-stage ring
-static int tile_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SPRC_GEMM_TILE");
-        v = e ? atoi(e) : 0;
+// SPRC_GEMM_TILE: 0 = automatic (default), 2 = 128x128, 4 = 256x256
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
     }
-    return v;
+    return n;
 }
 
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int KT_BYTES, int STAGES>
+template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT>
 static int launch_cfg(GemmParams p, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = STAGES * (BM + BN) * KT_BYTES;
-    if (((int64_t)p.K * sizeof(T)) % KT_BYTES != 0) {
-        set_error("sprc_gemm: K=%d is not a multiple of the K-tile", p.K);
-        return SPRC_EINVAL;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = 2 * (BM + BN) * 128;
+    // PERSIST=true (grid = CUs x residency, cross-tile prefetch) measured equal to one-WG-per-tile on MI355X while
+    // costing ~45 VGPRs (spills in the 256x256 tile): all tiles take the same time, so CUs stay in lockstep and the
+    // output-write bursts still coincide.  Kept in the source for a staggered variant; not instantiated.
+    constexpr bool PERSIST = false;
+    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN, PERSIST>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
     }
-    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN, KT_BYTES, STAGES>;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int grid = PERSIST ? (nwg < num_cus() * RESIDENT ? nwg : num_cus() * RESIDENT) : nwg;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, st, p);
+    SPRC_CHECK_LAUNCH("sprc_gemm");
+    return SPRC_OK;
+}
+
+template <typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN>
+static int launch_ring(GemmParams p, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = 4 * (BM + BN) * 64;
+    auto kern = gemm_ring_kernel<OutT, ACT, MAX32, WM, WN, TM, TN>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -320,13 +526,14 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), LDS, st, p);
-    SPRC_CHECK_LAUNCH("sprc_gemm");
+    SPRC_CHECK_LAUNCH("sprc_gemm(ring)");
     return SPRC_OK;
 }
 
 template <typename T, typename OutT, int ACT, bool MAX32>
 static int launch(const GemmParams& p, hipStream_t st) {
-    int cfg = tile_override();
+    static const int forced = env_int("SPRC_GEMM_TILE", 0);
+    int cfg = forced;
     if (cfg == 0) {
         // measured on MI355X (tools/gemm_bench.py): the 256x256 tile wins once its grid spans >= 4 rounds of the 256
         // CUs (ViT qkv / fc1, Q-Former K|V); below that (N = 1408-class and the small Q-Former GEMMs) two co-resident
@@ -334,15 +541,12 @@ static int launch(const GemmParams& p, hipStream_t st) {
         const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
         cfg = t256 >= 1024 ? 4 : 2;
     }
-    switch (cfg) {
-        case 1: return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 128, 1>(p, st);
-        case 2: return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 128, 2>(p, st);
-        case 3: return launch_cfg<T, OutT, ACT, MAX32, 4, 2, 2, 2, 128, 2>(p, st);
-        case 5: return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 64, 4>(p, st);
-        case 6: return launch_cfg<T, OutT, ACT, MAX32, 4, 2, 2, 2, 128, 3>(p, st);
-        case 7: return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 128, 4>(p, st);
-        default: return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 128, 2>(p, st);
+    if constexpr (sizeof(T) == 2) {
+        if (cfg == 10) return launch_ring<OutT, ACT, MAX32, 2, 4, 4, 2>(p, st);
+        if (cfg == 11) return launch_ring<OutT, ACT, MAX32, 2, 2, 2, 2>(p, st);
     }
+    if (cfg == 4 || cfg == 10) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
+    return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(p, st);
 }
 
 template <typename T>
