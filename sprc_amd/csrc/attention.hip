@@ -49,27 +49,48 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     const char* kbase = p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2;
     const char* vbase = p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2;
 
-    // ---- stage K (row-major, zero padded) ----
-    for (int it = tid; it < Tkp * (DHP / 8); it += 64 * NW) {
-        const int t = it / (DHP / 8), c = it % (DHP / 8);
-        u32x4 val = {0u, 0u, 0u, 0u};
-        if (t < p.Tk && c * 8 < dh) val = *reinterpret_cast<const u32x4*>(kbase + (int64_t)t * p.ldk * 2 + c * 16);
-        *reinterpret_cast<u32x4*>(sK + t * KROW + c * 16) = val;
-    }
-    // ---- stage V transposed: VT[d][key], two keys per 32-bit write ----
-    for (int it = tid; it < (Tkp / 2) * (DHP / 8); it += 64 * NW) {
-        const int kp = it % (Tkp / 2), c = it / (Tkp / 2);
-        const int t0 = kp * 2, t1 = t0 + 1;
-        u32x4 a = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
-        if (c * 8 < dh) {
-            if (t0 < p.Tk) a = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t0 * p.ldv * 2 + c * 16);
-            if (t1 < p.Tk) bb = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t1 * p.ldv * 2 + c * 16);
+    // ---- stage K (row-major, zero padded) and V transposed (VT[d][key], two keys per 32-bit write).  Global loads are
+    // issued in batches of UNR independent requests per thread before any LDS write, so a batch costs one memory
+    // latency instead of UNR (PMC before: 51 % of wave-cycles in s_waitcnt). ----
+    constexpr int NTH = 64 * NW, UNR = 8, CPR = DHP / 8;          // 16-B chunks per row
+    const int nK = Tkp * CPR;
+    for (int it0 = tid; it0 < nK; it0 += NTH * UNR) {
+        u32x4 val[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int it = it0 + u * NTH, t = it / CPR, c = it % CPR;
+            val[u] = u32x4{0u, 0u, 0u, 0u};
+            if (it < nK && t < p.Tk && c * 8 < dh) val[u] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)t * p.ldk * 2 + c * 16);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t lo = (a[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-            const uint32_t hi = (bb[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-            *reinterpret_cast<uint32_t*>(sV + (c * 8 + e) * VROW + t0 * 2) = lo | (hi << 16);
+        for (int u = 0; u < UNR; ++u) {
+            const int it = it0 + u * NTH, t = it / CPR, c = it % CPR;
+            if (it < nK) *reinterpret_cast<u32x4*>(sK + t * KROW + c * 16) = val[u];
+        }
+    }
+    const int nV = (Tkp / 2) * CPR;
+    for (int it0 = tid; it0 < nV; it0 += NTH * (UNR / 2)) {
+        u32x4 va[UNR / 2], vb[UNR / 2];
+#pragma unroll
+        for (int u = 0; u < UNR / 2; ++u) {
+            const int it = it0 + u * NTH, kp = it % (Tkp / 2), c = it / (Tkp / 2), t0 = kp * 2;
+            va[u] = vb[u] = u32x4{0u, 0u, 0u, 0u};
+            if (it < nV && c * 8 < dh) {
+                if (t0 < p.Tk) va[u] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t0 * p.ldv * 2 + c * 16);
+                if (t0 + 1 < p.Tk) vb[u] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(t0 + 1) * p.ldv * 2 + c * 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR / 2; ++u) {
+            const int it = it0 + u * NTH, kp = it % (Tkp / 2), c = it / (Tkp / 2), t0 = kp * 2;
+            if (it < nV) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t lo = (va[u][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                    const uint32_t hi = (vb[u][e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                    *reinterpret_cast<uint32_t*>(sV + (c * 8 + e) * VROW + t0 * 2) = lo | (hi << 16);
+                }
+            }
         }
     }
     // ---- additive mask in the log2 domain; -inf on padded keys ----
@@ -82,6 +103,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
 
     const float sc = p.scale * LOG2E;
     const int nqt = (p.Tq + 31) >> 5, nkt = Tkp >> 5;
+    const bool plain_tail = (p.Tk & 31) == 0;
     for (int qt = wave; qt < nqt; qt += NW) {
         // Q^T fragment (B operand): lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8]
         const int qrow = min(qt * 32 + r32, p.Tq - 1);
@@ -112,41 +134,55 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 32);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             }
-            // scale + mask; key of reg r: kt*32 + (r&3) + 8*(r>>2) + 4*half
-            float mx = -INFINITY;
+            float m_new, psum = 0.f;
+            if (p.key_mask == nullptr && (plain_tail || kt + 1 < nkt)) {
+                // no mask and no padded key in this tile: p = exp2(s*sc - m) with ONE fma per score
+                float mx = s[0];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(sM + kt * 32 + 8 * g + 4 * half);
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                m_new = fmaxf(m_run, mx * sc);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float val = s[g * 4 + e] * sc + mk[e];
-                    s[g * 4 + e] = val;
-                    mx = fmaxf(mx, val);
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_new));
+                    psum += s[r];
+                }
+            } else {
+                // scale + additive mask; key of reg r: kt*32 + (r&3) + 8*(r>>2) + 4*half
+                float mx = -INFINITY;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4*>(sM + kt * 32 + 8 * g + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s[g * 4 + e] = fmaf(s[g * 4 + e], sc, mk[e]);
+                        mx = fmaxf(mx, s[g * 4 + e]);
+                    }
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                m_new = fmaxf(m_run, mx);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+                    psum += s[r];
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[r] - m_new);
-                s[r] = pv;
-                psum += pv;
-            }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            if (__any(alpha != 1.0f)) {          // the running max moved for some query of this wave (rare after the first tiles)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
             // P^T fragments (B operand): k-slot j uses this lane's regs 8j..8j+7
             bf16x8 pf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 u32x4 pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
+                for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);   // v_cvt_pk_bf16_f32
                 pf[j] = __builtin_bit_cast(bf16x8, pk);
             }
             // O^T += V^T . P^T ; A operand lane (d = r32, half): keys {16j+4half+0..3, 16j+8+4half+0..3}

@@ -50,8 +50,10 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {   // round-to-ne
     return (uint16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {      // v_cvt_pk_bf16_f32 (RNE) on gfx950
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __host__ __device__ __forceinline__ int64_t map_row(const sprc_rowmap& m, int64_t r) {

@@ -40,6 +40,7 @@ struct GemmParams {
     int a_shift, a_stride, a_off;       // row maps (rows_per_group = 1<<shift, shift<0 -> identity)
     int c_shift, c_stride, c_off;
     int tiles_m, tiles_n;
+    int debug;                          // SPRC_GEMM_DEBUG ablations (timing experiments only): 1 = no global->LDS loads, 2 = no LDS reads
 };
 
 __device__ __forceinline__ int64_t map_row_s(int shift, int stride, int off, int r) {
@@ -85,6 +86,12 @@ template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);       // keep the MFMAs below the wait (guide rule 18)
+}
+
+// MFMA with the accumulator pinned in the AGPR half of the register file ("a" constraint).  hipcc left to itself keeps
+// the 128-register accumulator of the 256x256 tile in arch VGPRs.
+__device__ __forceinline__ void mfma_bf16_agpr(f32x16& acc, const u32x4& a, const u32x4& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
 // One K-tile (4 MFMA k-steps) of a wave's TM x TN accumulator block, hand software-pipelined.
@@ -176,9 +183,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         if constexpr (sizeof(OutT) == 2) {
                             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                             const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                            *reinterpret_cast<bf16x4*>(crow + col) = o;
+                            if (p.debug & 4) __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(crow + col));
+                            else *reinterpret_cast<bf16x4*>(crow + col) = o;
                         } else {
-                            *reinterpret_cast<f32x4*>(crow + col) = v;
+                            if (p.debug & 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(crow + col));
+                            else *reinterpret_cast<f32x4*>(crow + col) = v;
                         }
                     }
             } else {                                  // unaligned / ragged N: scalar path
@@ -342,30 +351,31 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Continuous-pipeline bf16 variant.  K is consumed in UNITS of 32 elements (64-byte rows = 2 MFMA k-steps); LDS holds a
-// ring of 4 units.  The workgroup barrier does NOT sit at a unit boundary (where every wave would then stall on LDS
-// latency with an empty fragment pipeline) but in the MIDDLE of each unit, between its two k-steps:
-//     k-step 0 of unit u:  issue fragment reads (u, k1)      | wait lgkmcnt | 8 MFMAs (u, k0)
-//     hand-over:           s_waitcnt vmcnt (own loads of unit u+1 landed) ; s_barrier ; issue loads of unit u+3
-//     k-step 1 of unit u:  issue fragment reads (u+1, k0)    | wait lgkmcnt | 8 MFMAs (u, k1)
-// After barrier u every wave's part of unit u+1 has landed (RAW) and every wave has finished reading unit u-1, whose
-// buffer receives unit u+3 (WAR).  Global->LDS loads therefore fly 2.5 units (~2500 MFMA cycles) ahead with COUNTED
-// vmcnt waits, and the fragment software pipeline never drains between units (guide T3/T4 applied to this tiling).
-// LDS rows are 64 B: slot swizzle f(row) = (row>>2)&3 keeps ds_read_b128 conflict-free (4 rows per 256-B bank row).
-template <typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmParams p) {
+// Anti-phase bf16 variant of the 256 x 256 tile (the schedule idea of the guide's 8-phase template, T3/T4/T5).
+// PMC on the lock-step kernel: matrix pipe busy 55 %, waves 54 % in issue stalls + 28 % in s_waitcnt/barrier -- the two
+// waves that share a SIMD hit their MFMA clusters at the same time and then sit at the K-tile barrier together.
+// Here the 8 waves form two groups (G0 = waves 0-3, G1 = waves 4-7; wave w and w+4 share a SIMD) that alternate:
+// in every barrier interval ONE group runs a 16-MFMA cluster (half a K-tile: k-steps 2h, 2h+1) while the OTHER reads its
+// next fragments from LDS (12 ds_read_b128) and waits for them.  G1 lags G0 by one interval (one extra s_barrier up
+// front, one fewer at the end), so per K-tile a wave executes  NC(t,0) | C(t,0) | NC(t,1) | C(t,1)  with a raw s_barrier
+// after each, and on every SIMD the matrix pipe always has exactly one producer.
+// Global->LDS loads of K-tile t+1 are issued in the NC intervals 4t..4t+2 and drained (vmcnt(0)) before the barrier that
+// closes interval 4t+3.  Hazards (global interval numbers, G1 = G0 + 1):
+//   RAW  tile t+1 is first read in interval 4t+4; every wave has waited for its own loads before the barrier closing 4t+3.
+//   WAR  buffer (t+1)&1 held tile t-1, whose last fragment reads completed (lgkmcnt(0)) before the barrier closing 4t-1;
+//        the earliest overwrite is issued in interval 4t.
+template <typename OutT, int ACT, bool MAX32>
+__global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef bf16_t T;
-    constexpr int UB = 64, RING = 4;
-    constexpr int NT = 64 * WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int UNIT_BYTES = (BM + BN) * UB;
-    constexpr int LA = BM * 4 / NT, LB = BN * 4 / NT, LU = LA + LB;    // 16-B chunks per thread per unit
-    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile/threads mismatch");
+    constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
+    constexpr int NT = 512, BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * KTB;
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT, LT = LA + LB;   // 4 + 4 global->LDS loads per thread per K-tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WN, wc = wave % WN;
+    const int wr = __builtin_amdgcn_readfirstlane(wave / WN), wc = wave % WN;   // wr doubles as the phase group (SGPR: barriers under it)
     const int r32 = lane & 31, half = lane >> 5;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int nu = p.K / 32;
+    const int nt = p.K / 64;
 
     int m0, n0;
     {
@@ -382,26 +392,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmParams p) {
     const char* w_src[LB];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        const int c = i * NT + tid, row = c >> 2, slot = (c & 3) ^ ((row >> 2) & 3);
+        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
         const int am = min(m0 + row, p.M - 1);
         a_src[i] = p.A + map_row_s(p.a_shift, p.a_stride, p.a_off, am) * p.lda_b + slot * 16;
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        const int c = i * NT + tid, row = c >> 2, slot = (c & 3) ^ ((row >> 2) & 3);
+        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
         const int wn = min(n0 + row, p.N - 1);
         w_src[i] = p.W + (int64_t)wn * p.ldw_b + slot * 16;
     }
-    auto issue_unit = [&](int u) {
-        char* dst = smem + (u & (RING - 1)) * UNIT_BYTES + wave * 1024;
-        const int64_t ko = (int64_t)u * UB;
-#pragma unroll
-        for (int i = 0; i < LA; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + ko), (lptr_t)(dst + i * NT * 16), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < LB; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + ko), (lptr_t)(dst + BM * UB + i * NT * 16), 16, 0, 0);
+    auto load_one = [&](auto j_, int tile) {                // j-th of the LT loads of K-tile `tile`
+        constexpr int j = decltype(j_)::value;
+        char* dst = smem + (tile & 1) * STAGE_BYTES + wave * 1024;
+        const int64_t ko = (int64_t)tile * KTB;
+        if constexpr (j < LA)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + ko), (lptr_t)(dst + j * NT * 16), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j - LA] + ko), (lptr_t)(dst + BM * KTB + (j - LA) * NT * 16), 16, 0, 0);
     };
+    auto load_tile = [&](int tile) { static_for<0, LT>([&](auto j_) { load_one(j_, tile); }); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -412,59 +422,68 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_ring_kernel(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-    const uint32_t c0 = (uint32_t)((half ^ ((r32 >> 2) & 3)) << 4);
-    const uint32_t a_off = lds0 + (wr * TM * 32 + r32) * UB, b_off = lds0 + BM * UB + (wc * TN * 32 + r32) * UB;
+    const uint32_t c0 = (uint32_t)((half ^ ((r32 >> 1) & 7)) << 4);
+    const uint32_t a_off = lds0 + (wr * TM * 32 + r32) * KTB, b_off = lds0 + BM * KTB + (wc * TN * 32 + r32) * KTB;
     u32x4 fa[2][TM], fb[2][TN];
-    auto reads = [&](auto buf_, int u, int kk) {                  // fragments of (unit u, k-step kk) -> fa/fb[buf]
-        constexpr int buf = decltype(buf_)::value;
-        const uint32_t o = (u & (RING - 1)) * UNIT_BYTES + (c0 ^ (kk << 5));
-        const uint32_t an = a_off + o, bn = b_off + o;
-        static_for<0, TM>([&](auto i) { fa[buf][i] = lds_read128<decltype(i)::value * 32 * UB>(an); });
-        static_for<0, TN>([&](auto i) { fb[buf][i] = lds_read128<decltype(i)::value * 32 * UB>(bn); });
+    auto reads = [&](int t, int h) {                        // fragments of K-tile t, k-steps 2h and 2h+1
+        const uint32_t so = (t & 1) * STAGE_BYTES;
+        static_for<0, 2>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            const uint32_t cn = c0 ^ ((2 * h + k) << 5), an = a_off + so + cn, bn = b_off + so + cn;
+            static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(an); });
+            static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(bn); });
+        });
     };
-    auto mfmas = [&](auto buf_) {
-        constexpr int buf = decltype(buf_)::value;
+    // 16 MFMAs; when `tile` >= 0, one global->LDS load of that K-tile is issued after every second MFMA
+    auto cluster = [&](int tile) {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[buf][ni]),
-                                                                      __builtin_bit_cast(bf16x8, fa[buf][mi]), acc[mi][ni], 0, 0, 0);
+        static_for<0, 16>([&](auto x_) {
+            constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[k][ni]),
+                                                                  __builtin_bit_cast(bf16x8, fa[k][mi]), acc[mi][ni], 0, 0, 0);
+            if constexpr ((x & 1) == 1) {
+                if (tile >= 0) load_one(std::integral_constant<int, (x >> 1)>{}, tile);
+            }
+        });
         __builtin_amdgcn_s_setprio(0);
     };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-
-    // prologue: units 0..2 in flight, unit 0 landed for everyone, first fragments requested
-    issue_unit(0);
-    if (nu > 1) issue_unit(1);
-    if (nu > 2) issue_unit(2);
-    if (nu > 2) wait_vmcnt<2 * LU>();
-    else if (nu > 1) wait_vmcnt<LU>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    reads(I0{}, 0, 0);
-
-    for (int u = 0; u < nu; ++u) {
-        reads(I1{}, u, 1);
-        wait_lgkmcnt<TM + TN>();
-        mfmas(I0{});
-        // hand-over (see header)
-        if (u + 2 < nu) wait_vmcnt<LU>();
-        else wait_vmcnt<0>();
+    auto barrier = [&]() {
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (u + 3 < nu) issue_unit(u + 3);
-        if (u + 1 < nu) {
-            reads(I0{}, u + 1, 0);
-            wait_lgkmcnt<TM + TN>();
-        } else {
-            wait_lgkmcnt<0>();
+    };
+
+    // prologue: K-tile 0 resident for everyone; G1 drops one interval behind
+    load_tile(0);
+    wait_vmcnt<0>();
+    barrier();
+    if (wr == 1) barrier();
+    // Global->LDS loads cost ~60 issue cycles each, so they live in the NC intervals (under the partner's MFMAs), never
+    // inside a cluster: G0 issues tile t+1 as 4 + 4 in NC(t,0) / NC(t,1) (global intervals 4t, 4t+2), G1 all 8 in its
+    // NC(t,0) (interval 4t+1); nothing may be issued in interval 4t+3, whose closing barrier publishes tile t+1.
+    const bool dbg_noload = p.debug & 1, dbg_noread = p.debug & 2;
+    if (dbg_noread) { reads(0, 0); wait_lgkmcnt<0>(); }
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt && !dbg_noload;
+        if (!dbg_noread) reads(t, 0);                       // NC(t,0)
+        if (more) {
+            static_for<0, LT / 2>([&](auto j_) { load_one(j_, t + 1); });
+            if (wr == 1) static_for<LT / 2, LT>([&](auto j_) { load_one(j_, t + 1); });
         }
-        mfmas(I1{});
+        wait_lgkmcnt<0>();
+        barrier();
+        cluster(-1);                                        // C(t,0)
+        barrier();
+        if (!dbg_noread) reads(t, 1);                       // NC(t,1)
+        if (more && wr == 0) static_for<LT / 2, LT>([&](auto j_) { load_one(j_, t + 1); });
+        wait_lgkmcnt<0>();
+        if (wr == 1) wait_vmcnt<0>();
+        barrier();
+        cluster(-1);                                        // C(t,1)
+        if (wr == 0) wait_vmcnt<0>();
+        barrier();
     }
+    if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
     gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
 }
@@ -514,19 +533,19 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     return SPRC_OK;
 }
 
-template <typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN>
-static int launch_ring(GemmParams p, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = 4 * (BM + BN) * 64;
-    auto kern = gemm_ring_kernel<OutT, ACT, MAX32, WM, WN, TM, TN>;
+template <typename OutT, int ACT, bool MAX32>
+static int launch_anti(GemmParams p, hipStream_t st) {
+    constexpr int LDS = 2 * 512 * 128;
+    auto kern = gemm_anti_kernel<OutT, ACT, MAX32>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), LDS, st, p);
-    SPRC_CHECK_LAUNCH("sprc_gemm(ring)");
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS, st, p);
+    SPRC_CHECK_LAUNCH("sprc_gemm(anti)");
     return SPRC_OK;
 }
 
@@ -542,10 +561,10 @@ static int launch(const GemmParams& p, hipStream_t st) {
         cfg = t256 >= 1024 ? 4 : 2;
     }
     if constexpr (sizeof(T) == 2) {
-        if (cfg == 10) return launch_ring<OutT, ACT, MAX32, 2, 4, 4, 2>(p, st);
-        if (cfg == 11) return launch_ring<OutT, ACT, MAX32, 2, 2, 2, 2>(p, st);
+        // 256x256 tile: anti-phase schedule by default (SPRC_GEMM_TILE=14 forces the lock-step kernel for A/B runs)
+        if (cfg == 4 || cfg == 10) return launch_anti<OutT, ACT, MAX32>(p, st);
     }
-    if (cfg == 4 || cfg == 10) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
+    if (cfg == 4 || cfg == 10 || cfg == 14) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
     return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(p, st);
 }
 
@@ -597,6 +616,8 @@ extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) {
         return SPRC_EUNSUPPORTED;
     }
     p.tiles_m = p.tiles_n = 0;
+    static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
+    p.debug = dbg;
     hipStream_t st = (hipStream_t)s;
     const double osz = a->max32 ? 4.0 / 32.0 : (double)dtype_size(a->out_dtype);
     ProfScope prof(a->dtype == SPRC_BF16 ? SPRC_K_GEMM_BF16 : SPRC_K_GEMM_F32, st, 2.0 * a->M * (double)a->N * a->K,
