@@ -40,6 +40,7 @@ struct GemmParams {
     int a_shift, a_stride, a_off;       // row maps (rows_per_group = 1<<shift, shift<0 -> identity)
     int c_shift, c_stride, c_off;
     int tiles_m, tiles_n;
+    int order;                          // tile order (tile_origin): 0 = 8-m grouped, n > 0 = groups of n n-tiles sweeping m
     int debug;                          // SPRC_GEMM_DEBUG ablations (timing experiments only): 1 = no global->LDS loads, 2 = no LDS reads
 };
 
@@ -126,6 +127,35 @@ __device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base
                                                                       __builtin_bit_cast(bf16x8, fa[cur][mi]), acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     });
+}
+
+// Tile order.  Block b runs on XCD b%8 (observed dispatch); the remap gives every XCD a CONTIGUOUS range of `pid`s, and
+// the pid -> (m,n) map walks a group of GN n-tiles over ALL m-tiles (m fastest inside the group).  The ~32 workgroups
+// resident on one XCD then form an 8(m) x 4(n) patch (12 operand panels per 32 tiles), and successive rounds on that XCD
+// keep the SAME 4 W panels (2.9 MB, L2-resident) while the A panels stream through once.  (mode 0: the earlier
+// 8-m-tile grouped order, where both operands change every round.)
+__device__ __forceinline__ void tile_origin(int vb, int nwg, int tiles_m, int tiles_n, int BM, int BN, int mode, int& m0, int& n0) {
+    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
+    const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    if (mode == 0) {
+        constexpr int GROUP_M = 8;
+        const int in_group = GROUP_M * tiles_n;
+        const int first_m = (pid / in_group) * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (pid % in_group) % gsz) * BM;
+        n0 = ((pid % in_group) / gsz) * BN;
+    } else {
+        const int GN = mode;                      // n-tiles per group
+        const int in_group = GN * tiles_m;
+        const int first_n = (pid / in_group) * GN;
+        const int gsz = min(tiles_n - first_n, GN);
+        const int rem = pid % in_group;
+        // inside a group: blocks of 8 m-tiles x gsz n-tiles, m fastest
+        const int blk = rem / (8 * gsz), inb = rem % (8 * gsz);
+        const int mrem = min(tiles_m - blk * 8, 8);
+        m0 = (blk * 8 + inb % mrem) * BM;
+        n0 = (first_n + inb / mrem) * BN;
+    }
 }
 
 // ---- epilogue (shared).  Transposed 32x32 D layout: m = rbase + (lane&31),  n = cbase + 8*(r>>2) + 4*(lane>>5) + (r&3) ----
@@ -228,17 +258,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
 
-    // ---- virtual block id -> tile: XCD-contiguous remap (bijective for any count), then grouped (8 m-tiles) order ----
-    auto tile_of = [&](int vb, int& m0, int& n0) {
-        const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
-        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-        constexpr int GROUP_M = 8;
-        const int in_group = GROUP_M * p.tiles_n;
-        const int first_m = (pid / in_group) * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        m0 = (first_m + (pid % in_group) % gsz) * BM;
-        n0 = ((pid % in_group) / gsz) * BN;
-    };
+    auto tile_of = [&](int vb, int& m0, int& n0) { tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0); };
 
     // ---- direct-to-LDS staging: lane fills physical slot (chunk&7) of row (chunk>>3) with logical slot^f(row) ----
     const char* a_src[LA];
@@ -378,16 +398,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     const int nt = p.K / 64;
 
     int m0, n0;
-    {
-        const int vb = blockIdx.x, xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
-        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-        constexpr int GROUP_M = 8;
-        const int in_group = GROUP_M * p.tiles_n;
-        const int first_m = (pid / in_group) * GROUP_M;
-        const int gsz = min(p.tiles_m - first_m, GROUP_M);
-        m0 = (first_m + (pid % in_group) % gsz) * BM;
-        n0 = ((pid % in_group) / gsz) * BN;
-    }
+    tile_origin(blockIdx.x, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
     const char* a_src[LA];
     const char* w_src[LB];
 #pragma unroll
@@ -526,6 +537,8 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     }
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    static const int order = env_int("SPRC_GEMM_ORDER", 0);     // 8-m grouped order is better for the K-heavy 128x128 GEMMs
+    p.order = order;
     const int nwg = p.tiles_m * p.tiles_n;
     const int grid = PERSIST ? (nwg < num_cus() * RESIDENT ? nwg : num_cus() * RESIDENT) : nwg;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, st, p);
@@ -544,6 +557,8 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     }
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
+    static const int order = env_int("SPRC_GEMM_ORDER", 4);     // W-resident groups of 4 n-tiles: +8 % on N = 9216, neutral else
+    p.order = order;
     hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm(anti)");
     return SPRC_OK;
@@ -618,6 +633,7 @@ extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) {
     p.tiles_m = p.tiles_n = 0;
     static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
     p.debug = dbg;
+    p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     hipStream_t st = (hipStream_t)s;
     const double osz = a->max32 ? 4.0 / 32.0 : (double)dtype_size(a->out_dtype);
     ProfScope prof(a->dtype == SPRC_BF16 ? SPRC_K_GEMM_BF16 : SPRC_K_GEMM_F32, st, 2.0 * a->M * (double)a->N * a->K,
