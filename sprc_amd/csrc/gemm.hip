@@ -379,18 +379,25 @@ __device__ __forceinline__ void wait_vmcnt() {
 // next fragments from LDS (12 ds_read_b128) and waits for them.  G1 lags G0 by one interval (one extra s_barrier up
 // front, one fewer at the end), so per K-tile a wave executes  NC(t,0) | C(t,0) | NC(t,1) | C(t,1)  with a raw s_barrier
 // after each, and on every SIMD the matrix pipe always has exactly one producer.
-// Global->LDS loads of K-tile t+1 are issued in the NC intervals 4t..4t+2 and drained (vmcnt(0)) before the barrier that
-// closes interval 4t+3.  Hazards (global interval numbers, G1 = G0 + 1):
-//   RAW  tile t+1 is first read in interval 4t+4; every wave has waited for its own loads before the barrier closing 4t+3.
-//   WAR  buffer (t+1)&1 held tile t-1, whose last fragment reads completed (lgkmcnt(0)) before the barrier closing 4t-1;
-//        the earliest overwrite is issued in interval 4t.
-template <typename OutT, int ACT, bool MAX32>
+// Staging (measured with s_memtime, tools/gemm_stamp.py: an NC interval carrying 12 ds_read_b128 + 4 global->LDS loads takes
+// 500-700 cycles to ISSUE against a 560-cycle cluster, and draining to vmcnt(0) costs up to 500 more): the K-tile is cut
+// into eight 8-KB pieces (64 rows x 128 B: A0..A3, B0..B3; group g reads A(2g), A(2g+1) and every B), two loads per thread
+// per piece, TWO pieces per NC interval and group (as SRSRC buffer loads: a global_load_lds with its 64-bit lane
+// addresses took 2-3x longer to issue), none inside the clusters, and every wait is a counted vmcnt(4) that leaves the
+// newest two pieces in flight:
+//   interval     4t-1            4t              4t+1            4t+2            4t+3
+//   issues       G1: A0 A1(t+1)  G0: B0 B1(t+1)  G1: B2 B3(t+1)  G0: A2 A3(t+1)  G1: A0 A1(t+2)
+//   first read of tile t+1: A0 A1 B* in 4t+4 (G0), A2 A3 in 4t+5 (G1); last read of tile t-1: A0 A1 in 4t-2, rest in 4t-1.
+//   RAW  the issuing wave retires a piece (counted vmcnt) before the barrier closing the interval BEFORE its first read:
+//        G0 after C(t,1) (4t+3: B0 B1 of t+1) and after NC(t,0) (4t: A2 A3 of t); G1 after NC(t,1) (4t+3: A0 A1 B2 B3 of
+//        t+1).  Every piece has >= 2 intervals between issue and wait.
+//   WAR  a piece is restaged >= 1 interval after the barrier that followed the last read of the region it overwrites.
+template <typename OutT, int ACT, bool MAX32, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef bf16_t T;
     constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
-    constexpr int NT = 512, BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * KTB;
-    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT, LT = LA + LB;   // 4 + 4 global->LDS loads per thread per K-tile
+    constexpr int BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * KTB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = __builtin_amdgcn_readfirstlane(wave / WN), wc = wave % WN;   // wr doubles as the phase group (SGPR: barriers under it)
     const int r32 = lane & 31, half = lane >> 5;
@@ -399,30 +406,38 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
 
     int m0, n0;
     tile_origin(blockIdx.x, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
-    const char* a_src[LA];
-    const char* w_src[LB];
+    // piece q of this group: q = 0, 1 issued in NC(t,0), q = 2, 3 in NC(t,1):  G0: B0 B1 | A2 A3    G1: B2 B3 | A0 A1
+    // (K-tile t+1, except G1's A0 A1 which already belong to K-tile t+2)
+    const int ltid = tid & 255, wg = wave & 3;
+    const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of the piece in its operand
+    const bool pc_is_a[4] = {false, false, true, true};
+    uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk in its operand (K-tile 0)
+    uint32_t pc_dst[4];                                     // LDS byte offset inside a stage (wave-uniform)
+    __amdgpu_buffer_rsrc_t pc_rsrc[4];                      // raw buffer over A or W: SGPR base + 32-bit offsets, no per-load VALU
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
-        const int am = min(m0 + row, p.M - 1);
-        a_src[i] = p.A + map_row_s(p.a_shift, p.a_stride, p.a_off, am) * p.lda_b + slot * 16;
-    }
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
-        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
-        const int wn = min(n0 + row, p.N - 1);
-        w_src[i] = p.W + (int64_t)wn * p.ldw_b + slot * 16;
+        for (int j = 0; j < 2; ++j) {
+            const int c = j * 256 + ltid, row = pc_row[q] + (c >> 3);
+            const int slot = (c & 7) ^ ((row >> 1) & 7);
+            const int64_t oa = map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) * p.lda_b;
+            const int64_t ow = (int64_t)min(n0 + row, p.N - 1) * p.ldw_b;
+            pc_off[q][j] = (uint32_t)(pc_is_a[q] ? oa : ow) + slot * 16;
+        }
+        pc_dst[q] = ((pc_is_a[q] ? 0 : BM) + pc_row[q]) * KTB + wg * 1024;
+        pc_rsrc[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pc_is_a[q] ? p.A : p.W), 0, 0xffffffff, 0x00020000);
     }
-    auto load_one = [&](auto j_, int tile) {                // j-th of the LT loads of K-tile `tile`
-        constexpr int j = decltype(j_)::value;
-        char* dst = smem + (tile & 1) * STAGE_BYTES + wave * 1024;
-        const int64_t ko = (int64_t)tile * KTB;
-        if constexpr (j < LA)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + ko), (lptr_t)(dst + j * NT * 16), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j - LA] + ko), (lptr_t)(dst + BM * KTB + (j - LA) * NT * 16), 16, 0, 0);
+    auto load_piece = [&](auto q_, auto j_, int tile) {     // j-th load (of 2) of piece q of K-tile `tile`
+        constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
+        char* dst = smem + (tile & 1) * STAGE_BYTES + pc_dst[q] + j * 4096;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(pc_rsrc[q], (lptr_t)dst, 16, pc_off[q][j], tile * KTB, 0, 0);
     };
-    auto load_tile = [&](int tile) { static_for<0, LT>([&](auto j_) { load_one(j_, tile); }); };
+    using std::integral_constant;
+    typedef integral_constant<int, 0> I0;
+    typedef integral_constant<int, 1> I1;
+    typedef integral_constant<int, 2> I2;
+    typedef integral_constant<int, 3> I3;
+    auto piece = [&](auto q_, int tile) { load_piece(q_, I0{}, tile); load_piece(q_, I1{}, tile); };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -445,18 +460,18 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(bn); });
         });
     };
-    // 16 MFMAs; when `tile` >= 0, one global->LDS load of that K-tile is issued after every second MFMA
-    auto cluster = [&](int tile) {
+    auto cluster = [&]() {                                  // 16 MFMAs: k-steps 2h, 2h+1 of the 128 x 64 wave tile
         __builtin_amdgcn_s_setprio(1);
         static_for<0, 16>([&](auto x_) {
             constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[k][ni]),
                                                                   __builtin_bit_cast(bf16x8, fa[k][mi]), acc[mi][ni], 0, 0, 0);
-            if constexpr ((x & 1) == 1) {
-                if (tile >= 0) load_one(std::integral_constant<int, (x >> 1)>{}, tile);
-            }
         });
         __builtin_amdgcn_s_setprio(0);
+    };
+    auto wait_vm = [&](bool newer) {                        // leave the newest two pieces (4 loads) in flight, if issued
+        if (newer) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
     };
     auto barrier = [&]() {
         asm volatile("" ::: "memory");
@@ -464,39 +479,69 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         asm volatile("" ::: "memory");
     };
 
-    // prologue: K-tile 0 resident for everyone; G1 drops one interval behind
-    load_tile(0);
-    wait_vmcnt<0>();
+    // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
+    // flight, G1 one interval behind
+    static_for<0, 4>([&](auto q_) { piece(q_, 0); });
+    if (wr == 1 && nt > 1) { piece(I2{}, 1); piece(I3{}, 1); wait_vmcnt<4>(); }
+    else wait_vmcnt<0>();
     barrier();
     if (wr == 1) barrier();
-    // Global->LDS loads cost ~60 issue cycles each, so they live in the NC intervals (under the partner's MFMAs), never
-    // inside a cluster: G0 issues tile t+1 as 4 + 4 in NC(t,0) / NC(t,1) (global intervals 4t, 4t+2), G1 all 8 in its
-    // NC(t,0) (interval 4t+1); nothing may be issued in interval 4t+3, whose closing barrier publishes tile t+1.
     const bool dbg_noload = p.debug & 1, dbg_noread = p.debug & 2;
     if (dbg_noread) { reads(0, 0); wait_lgkmcnt<0>(); }
-    for (int t = 0; t < nt; ++t) {
-        const bool more = t + 1 < nt && !dbg_noload;
-        if (!dbg_noread) reads(t, 0);                       // NC(t,0)
-        if (more) {
-            static_for<0, LT / 2>([&](auto j_) { load_one(j_, t + 1); });
-            if (wr == 1) static_for<LT / 2, LT>([&](auto j_) { load_one(j_, t + 1); });
+    // STAMP build (tools only): s_memtime at the phase boundaries of K-tile 8, written over p.resid by waves 0 and 4 of WG 0
+    uint64_t ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](auto i_, int t) {
+        if constexpr (STAMP) {
+            if (t == 8) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();
         }
+    };
+    for (int t = 0; t < nt; ++t) {
+        const bool n1 = t + 1 < nt && !dbg_noload, n2 = t + 2 < nt && !dbg_noload;
+        const int t_p2 = wr ? t + 2 : t + 1;                // K-tile of the pieces issued in NC(t,1)
+        const bool has_p2 = wr ? n2 : n1;
+        stamp(integral_constant<int, 0>{}, t);
+        if (!dbg_noread) reads(t, 0);                       // NC(t,0)
+        if (n1) { piece(I0{}, t + 1); piece(I1{}, t + 1); }
+        stamp(integral_constant<int, 1>{}, t);
         wait_lgkmcnt<0>();
+        if (wr == 0) wait_vm(n1);                           // A2 A3 of t landed (G1 reads them in the next interval)
+        stamp(integral_constant<int, 2>{}, t);
         barrier();
-        cluster(-1);                                        // C(t,0)
+        stamp(integral_constant<int, 3>{}, t);
+        cluster();                                          // C(t,0)
+        stamp(integral_constant<int, 4>{}, t);
         barrier();
+        stamp(integral_constant<int, 5>{}, t);
         if (!dbg_noread) reads(t, 1);                       // NC(t,1)
-        if (more && wr == 0) static_for<LT / 2, LT>([&](auto j_) { load_one(j_, t + 1); });
+        if (has_p2) { piece(I2{}, t_p2); piece(I3{}, t_p2); }
+        stamp(integral_constant<int, 6>{}, t);
         wait_lgkmcnt<0>();
-        if (wr == 1) wait_vmcnt<0>();
+        if (wr == 1) wait_vm(n2);                           // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
+        stamp(integral_constant<int, 7>{}, t);
         barrier();
-        cluster(-1);                                        // C(t,1)
-        if (wr == 0) wait_vmcnt<0>();
+        stamp(integral_constant<int, 8>{}, t);
+        cluster();                                          // C(t,1)
+        stamp(integral_constant<int, 9>{}, t);
+        if (wr == 0) wait_vm(n1);                           // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
+        stamp(integral_constant<int, 10>{}, t);
         barrier();
+        stamp(integral_constant<int, 11>{}, t);
     }
     if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
     gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
+    if constexpr (STAMP) {
+        if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) {
+            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + (wave >> 2) * 16;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) o[i] = ts[i];
+        }
+    }
+}
+
+static int64_t map_row_host(int shift, int stride, int off, int r) {
+    if (shift < 0) return r;
+    return (int64_t)(r >> shift) * stride + (r & ((1 << shift) - 1)) + off;
 }
 
 static int ilog2_exact(int v) {
@@ -550,6 +595,18 @@ template <typename OutT, int ACT, bool MAX32>
 static int launch_anti(GemmParams p, hipStream_t st) {
     constexpr int LDS = 2 * 512 * 128;
     auto kern = gemm_anti_kernel<OutT, ACT, MAX32>;
+    if constexpr (sizeof(OutT) == 2 && ACT == SPRC_ACT_NONE && !MAX32) {
+        if ((p.debug & 64) && p.resid != nullptr) {         // phase-timestamp build (tools/gemm_stamp.py)
+            auto sk = gemm_anti_kernel<OutT, ACT, MAX32, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            p.tiles_m = (p.M + 255) / 256;
+            p.tiles_n = (p.N + 255) / 256;
+            p.order = 4;
+            hipLaunchKernelGGL(sk, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS, st, p);
+            SPRC_CHECK_LAUNCH("sprc_gemm(anti, stamp)");
+            return SPRC_OK;
+        }
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -564,20 +621,52 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     return SPRC_OK;
 }
 
+// largest byte offset the operands are addressed with (the 256x256 kernel uses 32-bit buffer offsets)
+static bool fits_u32(const GemmParams& p) {
+    const int64_t last_a = map_row_host(p.a_shift, p.a_stride, p.a_off, p.M - 1);
+    return (last_a + 1) * p.lda_b < (int64_t)1 << 32 && (int64_t)p.N * p.ldw_b < (int64_t)1 << 32;
+}
+
 template <typename T, typename OutT, int ACT, bool MAX32>
 static int launch(const GemmParams& p, hipStream_t st) {
     static const int forced = env_int("SPRC_GEMM_TILE", 0);
     int cfg = forced;
-    if (cfg == 0) {
-        // measured on MI355X (tools/gemm_bench.py): the 256x256 tile wins once its grid spans >= 4 rounds of the 256
-        // CUs (ViT qkv / fc1, Q-Former K|V); below that (N = 1408-class and the small Q-Former GEMMs) two co-resident
-        // 128x128 workgroups per CU hide each other's prologue/epilogue better.
-        const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        cfg = t256 >= 1024 ? 4 : 2;
-    }
     if constexpr (sizeof(T) == 2) {
+        const bool anti_ok = fits_u32(p);
+        if (cfg == 0) {
+            // Cost model in units of one 256x256xK tile on a CU (measured on MI355X, tools/gemm_shapes.py):
+            //   B  256x256 anti-phase kernel, one WG per CU:            rounds(M) x 1
+            //   A  128x128 kernel, two co-resident WGs per CU:           rounds of 2 x CUs tiles x 0.7
+            //   C  B on the first M & ~255 rows + A on the remainder:    rounds(M & ~255) x 1 + 0.4
+            // C matters when the last, partial 256-row panel costs a whole extra round: the ViT GEMMs have
+            // M = 128 x 257 = 128.5 panels, so N = 1408 is 774 tiles = 3.02 rounds (fc2: 732 us whole, 562 + 77 us peeled).
+            const int ncu = num_cus();
+            const int64_t tn256 = (p.N + 255) / 256;
+            auto rounds256 = [&](int m) { return (double)((((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
+            const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+            const double cA = 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu));
+            const double cB = anti_ok ? rounds256(p.M) : 1e30;
+            const int Mm = p.M & ~255, rem = p.M - Mm;
+            static const int peel = env_int("SPRC_GEMM_PEEL", 1);
+            const bool can_peel = peel && anti_ok && !MAX32 && rem > 0 && Mm > 0 && p.a_shift < 0 && p.c_shift < 0;
+            const double cC = can_peel ? rounds256(Mm) + 0.4 : 1e30;
+            if (cC < 0.95 * (cA < cB ? cA : cB)) {
+                GemmParams pm = p, pt = p;
+                pm.M = Mm;
+                pt.M = rem;
+                pt.A = p.A + (int64_t)Mm * p.lda_b;
+                pt.C = reinterpret_cast<char*>(p.C) + (int64_t)Mm * p.ldc * (MAX32 ? 4 : (int64_t)sizeof(OutT));
+                if (p.resid != nullptr) pt.resid = p.resid + (int64_t)Mm * p.ldr;
+                const int rc = launch_anti<OutT, ACT, MAX32>(pm, st);
+                if (rc != SPRC_OK) return rc;
+                return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(pt, st);
+            }
+            cfg = cB <= cA ? 4 : 2;
+        }
         // 256x256 tile: anti-phase schedule by default (SPRC_GEMM_TILE=14 forces the lock-step kernel for A/B runs)
-        if (cfg == 4 || cfg == 10) return launch_anti<OutT, ACT, MAX32>(p, st);
+        if ((cfg == 4 || cfg == 10) && anti_ok) return launch_anti<OutT, ACT, MAX32>(p, st);
+    } else {
+        if (cfg == 0) cfg = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024 ? 4 : 2;
     }
     if (cfg == 4 || cfg == 10 || cfg == 14) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
     return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(p, st);
