@@ -49,16 +49,18 @@ __device__ __forceinline__ int64_t map_row_s(int shift, int stride, int off, int
     return (int64_t)(r >> shift) * stride + (r & ((1 << shift) - 1)) + off;
 }
 
-// erf for the bf16 epilogue: Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 (far below bf16 resolution)
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float y = fmaf(1.061405429f, t, -1.453152027f);
-    y = fmaf(y, t, 1.421413741f);
-    y = fmaf(y, t, -0.284496736f);
-    y = fmaf(y, t, 0.254829592f);
-    y = 1.0f - y * t * __expf(-ax * ax);
-    return copysignf(y, x);
+// GELU of the bf16 epilogue: x * Phi(x) with Phi(x) ~ 1 / (1 + 2^(x (k0 + k1 t + k2 t^2))), t = min(x^2, 80) -- a logistic
+// approximation of the normal CDF with a fitted odd quintic exponent: |gelu error| <= 2.6e-5 for every finite x (checked
+// in fp32 on [-40, 40]), an order below the bf16 rounding of the stored value.  9 VALU ops per value.  The epilogue runs
+// with the matrix pipe idle and is VALU-issue bound (4 cycles per wave64 op, two waves per SIMD), so it costs what it
+// counts: on the 750-us ViT fc1 GEMM the erf form (A&S 7.1.26, ~17 ops) took 150 us, a degree-8 Horner polynomial (13 ops,
+// packed or scalar, pinned constants or literals -- all the same) 106-117 us, x*sigmoid(1.702x) (5 ops) 40 us.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float t = fminf(x * x, 80.0f);
+    float q = fmaf(t, 1.014263136e-03f, -1.067757234e-01f);
+    q = fmaf(q, t, -2.301121235e+00f);
+    const float e = __builtin_amdgcn_exp2f(x * q);          // +inf for very negative x: rcp(inf) = 0
+    return x * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 template <typename T> struct Frag;
@@ -67,6 +69,15 @@ template <> struct Frag<float> { typedef f32x4 type; };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Raw-buffer (SRSRC) 16-B-per-lane load straight into LDS.  Kept in NON-template helpers: this hipcc silently drops the
+// host stub of a kernel TEMPLATE whose dependent code calls the buffer builtins directly.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t voffset, int soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds_dst, 16, voffset, soffset, 0, 0);
+}
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -162,6 +173,20 @@ __device__ __forceinline__ void tile_origin(int vb, int nwg, int tiles_m, int ti
 template <typename T, typename OutT, int ACT, bool MAX32, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int cm0, int cn0, int wr, int wc,
                                               int r32, int half, bool vec_ok) {
+    // bias of this lane's 4-column groups: loaded ONCE, before any of it is needed (it used to be one load + vmcnt(0) round
+    // trip per group and row block: 32 serial L2 latencies per thread)
+    f32x4 bv[TN][4];
+    if constexpr (!MAX32) {
+        if (vec_ok) {
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = cn0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
+                    bv[ni][g] = (p.bias != nullptr && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int row = cm0 + (wr * TM + mi) * 32 + r32;
@@ -200,16 +225,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         const int col = cn0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
                         if (!(row_ok && col < p.N)) continue;
                         f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-                        if (p.bias != nullptr) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bv[ni][g][e];      // element-wise on purpose: a vector add becomes v_pk_add_f32 (slower)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             if constexpr (ACT == SPRC_ACT_GELU) {
-                                if constexpr (sizeof(T) == 2) v[e] = 0.5f * v[e] * (1.0f + erf_as(v[e] * 0.70710678118654752440f));
+                                if constexpr (sizeof(T) == 2) v[e] = gelu_fast(v[e]);
                                 else v[e] = gelu_erf(v[e]);
                             }
                             if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
                         }
-                        if (rrow != nullptr) v += rv[ni][g];
+                        if (rrow != nullptr) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += rv[ni][g][e];
+                        }
                         if constexpr (sizeof(OutT) == 2) {
                             typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
                             const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
@@ -229,7 +258,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         if (!(row_ok && col < p.N)) continue;
                         float v = acc[mi][ni][r] + (p.bias ? p.bias[col] : 0.f);
                         if constexpr (ACT == SPRC_ACT_GELU) {
-                            if constexpr (sizeof(T) == 2) v = 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));
+                            if constexpr (sizeof(T) == 2) v = gelu_fast(v);
                             else v = gelu_erf(v);
                         }
                         if constexpr (ACT == SPRC_ACT_QUICKGELU) v = quick_gelu(v);
@@ -242,7 +271,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
 }
 
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, bool PERSIST>
+template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KT_BYTES = 128;
@@ -258,35 +287,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
 
-    auto tile_of = [&](int vb, int& m0, int& n0) { tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0); };
-
     // ---- direct-to-LDS staging: lane fills physical slot (chunk&7) of row (chunk>>3) with logical slot^f(row) ----
-    const char* a_src[LA];
-    const char* w_src[LB];
-    auto setup = [&](int m0, int n0) {
+    // SRSRC buffer loads (workgroup-uniform base = first row of the tile, 32-bit lane offsets, K-tile offset in an SGPR):
+    // no per-load address VALU, and they issue 2-3x faster than global_load_lds with 64-bit lane addresses.
+    int m0, n0;
+    tile_origin(blockIdx.x, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
+    const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
+    const char* a_base = p.A + a_row0 * p.lda_b;            // resources are rebuilt from these at each use (loop-invariant SGPRs)
+    const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
+    uint32_t a_src[LA], w_src[LB];
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
-            const int am = min(m0 + row, p.M - 1);
-            a_src[i] = p.A + map_row_s(p.a_shift, p.a_stride, p.a_off, am) * p.lda_b + slot * 16;
-        }
+    for (int i = 0; i < LA; ++i) {
+        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
+        const int am = min(m0 + row, p.M - 1);
+        a_src[i] = (uint32_t)((map_row_s(p.a_shift, p.a_stride, p.a_off, am) - a_row0) * p.lda_b) + slot * 16;
+    }
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
-            const int wn = min(n0 + row, p.N - 1);
-            w_src[i] = p.W + (int64_t)wn * p.ldw_b + slot * 16;
-        }
-    };
+    for (int i = 0; i < LB; ++i) {
+        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
+        w_src[i] = (uint32_t)((int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldw_b) + slot * 16;
+    }
     auto stage_one = [&](auto j_, char* dst, int64_t ko) {      // j-th of the LA+LB loads of one K-tile
         constexpr int j = decltype(j_)::value;
         if constexpr (j < LA)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[j] + ko), (lptr_t)(dst + j * NT * 16), 16, 0, 0);
+            buffer_load_lds16(make_rsrc(a_base), dst + j * NT * 16, a_src[j], (int)ko);
         else
-            __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j - LA] + ko), (lptr_t)(dst + BM * KT_BYTES + (j - LA) * NT * 16), 16, 0, 0);
-    };
-    auto stage = [&](int buf, int64_t ko) {
-        char* dst = smem + buf * STAGE_BYTES + wave * 1024;
-        static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst, ko); });
+            buffer_load_lds16(make_rsrc(w_base), dst + BM * KT_BYTES + (j - LA) * NT * 16, w_src[j - LA], (int)ko);
     };
 
     const int sw = (r32 >> 1) & 7;
@@ -295,12 +321,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const uint32_t c0 = (uint32_t)((half ^ sw) << 4);
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
 
-    int vb = blockIdx.x, m0, n0;
-    tile_of(vb, m0, n0);
-    setup(m0, n0);
-    stage(0, 0);                                                // K-tile 0 of the first tile
+    {                                                           // K-tile 0
+        char* dst0 = smem + wave * 1024;
+        static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst0, 0); });
+    }
 
-    while (true) {
+    {
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
@@ -322,7 +348,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
                     if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
                 });
             } else {
-                if (more) stage((t + 1) & 1, ko);
+                if (more) {
+                    char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
+                    static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst, ko); });
+                }
                 const char* st = smem + (t & 1) * STAGE_BYTES;
                 frag_t fa[2][TM], fb[2][TN];
                 auto load = [&](int buf, int kk) {
@@ -348,20 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
             }
         }
 
-        // ---- hand over: prefetch the next tile's K-tile 0, then write this tile out ----
-        const int cm0 = m0, cn0 = n0;
-        const int vb_next = vb + gridDim.x;
-        const bool has_next = PERSIST && vb_next < nwg;
-        __syncthreads();                     // every wave is done reading LDS
-        if (has_next) {
-            tile_of(vb_next, m0, n0);
-            setup(m0, n0);
-            stage(0, 0);
-        }
-
-        gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, cm0, cn0, wr, wc, r32, half, vec_ok);
-        if (!has_next) break;
-        vb = vb_next;
+        gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
     }
 }
 
@@ -411,26 +427,29 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     const int ltid = tid & 255, wg = wave & 3;
     const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of the piece in its operand
     const bool pc_is_a[4] = {false, false, true, true};
-    uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk in its operand (K-tile 0)
+    uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk from the tile's first row (K-tile 0)
     uint32_t pc_dst[4];                                     // LDS byte offset inside a stage (wave-uniform)
     __amdgpu_buffer_rsrc_t pc_rsrc[4];                      // raw buffer over A or W: SGPR base + 32-bit offsets, no per-load VALU
+    const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
+    const char* a_base = p.A + a_row0 * p.lda_b;
+    const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int c = j * 256 + ltid, row = pc_row[q] + (c >> 3);
             const int slot = (c & 7) ^ ((row >> 1) & 7);
-            const int64_t oa = map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) * p.lda_b;
-            const int64_t ow = (int64_t)min(n0 + row, p.N - 1) * p.ldw_b;
+            const int64_t oa = (map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b;
+            const int64_t ow = (int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldw_b;
             pc_off[q][j] = (uint32_t)(pc_is_a[q] ? oa : ow) + slot * 16;
         }
         pc_dst[q] = ((pc_is_a[q] ? 0 : BM) + pc_row[q]) * KTB + wg * 1024;
-        pc_rsrc[q] = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pc_is_a[q] ? p.A : p.W), 0, 0xffffffff, 0x00020000);
+        pc_rsrc[q] = make_rsrc(pc_is_a[q] ? a_base : w_base);
     }
     auto load_piece = [&](auto q_, auto j_, int tile) {     // j-th load (of 2) of piece q of K-tile `tile`
         constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
         char* dst = smem + (tile & 1) * STAGE_BYTES + pc_dst[q] + j * 4096;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(pc_rsrc[q], (lptr_t)dst, 16, pc_off[q][j], tile * KTB, 0, 0);
+        buffer_load_lds16(pc_rsrc[q], dst, pc_off[q][j], tile * KTB);
     };
     using std::integral_constant;
     typedef integral_constant<int, 0> I0;
@@ -479,6 +498,13 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         asm volatile("" ::: "memory");
     };
 
+    if ((p.debug & 256) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        // experiment: first-round workgroups of every other CU start half a tile late, so that the epilogue (output
+        // write burst) of one half of the chip overlaps the main loop of the other half
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        const uint64_t wait = (uint64_t)nt * 1500;          // shader cycles: ~half of a tile (nt x ~3000 cycles)
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
     // flight, G1 one interval behind
     static_for<0, 4>([&](auto q_) { piece(q_, 0); });
@@ -539,11 +565,6 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     }
 }
 
-static int64_t map_row_host(int shift, int stride, int off, int r) {
-    if (shift < 0) return r;
-    return (int64_t)(r >> shift) * stride + (r & ((1 << shift) - 1)) + off;
-}
-
 static int ilog2_exact(int v) {
     if (v <= 0) return -1;
     int s = 0;
@@ -570,11 +591,10 @@ static int num_cus() {
 template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT>
 static int launch_cfg(GemmParams p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = 2 * (BM + BN) * 128;
-    // PERSIST=true (grid = CUs x residency, cross-tile prefetch) measured equal to one-WG-per-tile on MI355X while
-    // costing ~45 VGPRs (spills in the 256x256 tile): all tiles take the same time, so CUs stay in lockstep and the
-    // output-write bursts still coincide.  Kept in the source for a staggered variant; not instantiated.
-    constexpr bool PERSIST = false;
-    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN, PERSIST>;
+    // (A persistent variant -- grid = CUs x residency with the next tile's first K-tile prefetched before the epilogue --
+    // measured equal to one workgroup per tile on MI355X while costing ~45 VGPRs: all tiles take the same time, so the
+    // CUs stay in lockstep and the output-write bursts still coincide.  Removed.)
+    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -585,8 +605,7 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     static const int order = env_int("SPRC_GEMM_ORDER", 0);     // 8-m grouped order is better for the K-heavy 128x128 GEMMs
     p.order = order;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int grid = PERSIST ? (nwg < num_cus() * RESIDENT ? nwg : num_cus() * RESIDENT) : nwg;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WM * WN), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WM * WN), LDS, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm");
     return SPRC_OK;
 }
@@ -621,10 +640,11 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     return SPRC_OK;
 }
 
-// largest byte offset the operands are addressed with (the 256x256 kernel uses 32-bit buffer offsets)
+// The kernels address a tile with 32-bit offsets from its first row: the rows of one (<= 256-row) tile must span < 4 GiB.
 static bool fits_u32(const GemmParams& p) {
-    const int64_t last_a = map_row_host(p.a_shift, p.a_stride, p.a_off, p.M - 1);
-    return (last_a + 1) * p.lda_b < (int64_t)1 << 32 && (int64_t)p.N * p.ldw_b < (int64_t)1 << 32;
+    const int64_t span_a = p.a_shift < 0 ? 256 : (int64_t)((256 >> p.a_shift) + 2) * p.a_stride;
+    const int64_t kbytes = (int64_t)p.K * 4;
+    return span_a * p.lda_b + kbytes < ((int64_t)1 << 32) && 256 * p.ldw_b + kbytes < ((int64_t)1 << 32);
 }
 
 template <typename T, typename OutT, int ACT, bool MAX32>
@@ -632,7 +652,6 @@ static int launch(const GemmParams& p, hipStream_t st) {
     static const int forced = env_int("SPRC_GEMM_TILE", 0);
     int cfg = forced;
     if constexpr (sizeof(T) == 2) {
-        const bool anti_ok = fits_u32(p);
         if (cfg == 0) {
             // Cost model in units of one 256x256xK tile on a CU (measured on MI355X, tools/gemm_shapes.py):
             //   B  256x256 anti-phase kernel, one WG per CU:            rounds(M) x 1
@@ -645,10 +664,10 @@ static int launch(const GemmParams& p, hipStream_t st) {
             auto rounds256 = [&](int m) { return (double)((((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
             const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
             const double cA = 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu));
-            const double cB = anti_ok ? rounds256(p.M) : 1e30;
+            const double cB = rounds256(p.M);
             const int Mm = p.M & ~255, rem = p.M - Mm;
             static const int peel = env_int("SPRC_GEMM_PEEL", 1);
-            const bool can_peel = peel && anti_ok && !MAX32 && rem > 0 && Mm > 0 && p.a_shift < 0 && p.c_shift < 0;
+            const bool can_peel = peel && !MAX32 && rem > 0 && Mm > 0 && p.a_shift < 0 && p.c_shift < 0;
             const double cC = can_peel ? rounds256(Mm) + 0.4 : 1e30;
             if (cC < 0.95 * (cA < cB ? cA : cB)) {
                 GemmParams pm = p, pt = p;
@@ -664,7 +683,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
             cfg = cB <= cA ? 4 : 2;
         }
         // 256x256 tile: anti-phase schedule by default (SPRC_GEMM_TILE=14 forces the lock-step kernel for A/B runs)
-        if ((cfg == 4 || cfg == 10) && anti_ok) return launch_anti<OutT, ACT, MAX32>(p, st);
+        if (cfg == 4 || cfg == 10) return launch_anti<OutT, ACT, MAX32>(p, st);
     } else {
         if (cfg == 0) cfg = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024 ? 4 : 2;
     }
@@ -717,6 +736,10 @@ extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) {
     p.c_shift = ilog2_exact(a->cmap.rows_per_group); p.c_stride = a->cmap.group_stride; p.c_off = a->cmap.group_offset;
     if (p.a_shift == -2 || p.c_shift == -2) {
         set_error("sprc_gemm: rows_per_group must be a power of two");
+        return SPRC_EUNSUPPORTED;
+    }
+    if (!fits_u32(p)) {
+        set_error("sprc_gemm: a 256-row tile of A or W spans >= 4 GiB (lda=%lld ldw=%lld)", (long long)a->lda, (long long)a->ldw);
         return SPRC_EUNSUPPORTED;
     }
     p.tiles_m = p.tiles_n = 0;

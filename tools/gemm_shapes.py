@@ -9,7 +9,7 @@ for spec in sys.argv[1:]:
     f = spec.split(",")
     M, N, K = (int(x) for x in f[:3])
     o32 = "f32" in f[3:]
-    act = L.ACT_GELU if "gelu" in f[3:] else L.ACT_NONE
+    act = L.ACT_GELU if "gelu" in f[3:] else L.ACT_QUICKGELU if "qgelu" in f[3:] else L.ACT_NONE
     A = torch.randn((M, K), device="cuda").to(torch.bfloat16)
     W = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
     b = torch.randn((N,), device="cuda")
