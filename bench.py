@@ -162,6 +162,15 @@ def main():
                        "tflops": round(prof[j].flops / max(prof[j].ms, 1e-9) / 1e9, 1),
                        "alg_GBs": round(prof[j].bytes / max(prof[j].ms, 1e-9) / 1e6, 1)}
                    for j, n in enumerate(L.K_CLASSES) if prof[j].launches}
+        # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside this process, so the figure comes from the
+        # committed rocprofv3 passes over this same command (tools/profile_bench.sh -> profiles/r01_traffic.json)
+        traffic, traffic_src = None, None
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if a.dtype == "bf16" and a.backbone == "pretrain" and os.path.exists(tj) and pe.launches:
+            with open(tj) as f:
+                per_step = json.load(f)["gemm_bytes_per_step"]["total"]
+            traffic = round(per_step / (pe.launches / a.steps), 1)
+            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only passes)"
         out = {
             "metric": "gallery images encoded+ranked/sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -172,7 +181,9 @@ def main():
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
                        "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}"},
             "roofline": {"bound": "mfma", "kernel": "sprc::gemm_kernel<%s>" % a.dtype, "achieved": round(ach, 1), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                         "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
+                         "alg_bytes_per_launch": round(pe.bytes / max(pe.launches, 1), 1),
                          "launches": int(pe.launches), "avg_launch_ms": round(pe.ms / max(pe.launches, 1), 4),
                          "alg_flops_per_launch": round(pe.flops / max(pe.launches, 1), 1)},
             "kernels": kernels,
