@@ -75,6 +75,9 @@ typedef struct {
     const float* bias;
     const float* resid; int64_t ldr;
     void* C;        int64_t ldc;  sprc_rowmap cmap;
+    /* optional device scratch the call may use for split-K partial sums (never read afterwards); NULL/0 = none.
+     * 8 * 128 * N * 4 bytes lets the <= 128 remainder rows of a K >= 4096 product be reduced by 8 workgroups per tile. */
+    void* scratch;  size_t scratch_bytes;
 } sprc_gemm_args;
 int sprc_gemm(const sprc_gemm_args* a, sprc_stream s);
 

@@ -24,7 +24,8 @@ class RowMap(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("dtype", i32), ("out_dtype", i32), ("act", i32), ("max32", i32),
                 ("A", vp), ("lda", i64), ("amap", RowMap), ("W", vp), ("ldw", i64), ("bias", vp),
-                ("resid", vp), ("ldr", i64), ("C", vp), ("ldc", i64), ("cmap", RowMap)]
+                ("resid", vp), ("ldr", i64), ("C", vp), ("ldc", i64), ("cmap", RowMap),
+                ("scratch", vp), ("scratch_bytes", C.c_size_t)]
 
 
 class LayerNormArgs(C.Structure):

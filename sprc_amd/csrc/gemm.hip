@@ -40,7 +40,10 @@ struct GemmParams {
     int a_shift, a_stride, a_off;       // row maps (rows_per_group = 1<<shift, shift<0 -> identity)
     int c_shift, c_stride, c_off;
     int tiles_m, tiles_n;
+    float* scratch; int64_t scratch_elems;   // optional caller scratch (split-K partials)
     int order;                          // tile order (tile_origin): 0 = 8-m grouped, n > 0 = groups of n n-tiles sweeping m
+    int ksplit;                         // > 1: split-K launch of the 128x128 kernel (grid = tiles x ksplit), raw fp32 partials
+    int64_t split_stride;               // elements between the partial planes of consecutive K splits
     int debug;                          // SPRC_GEMM_DEBUG ablations (timing experiments only): 1 = no global->LDS loads, 2 = no LDS reads
 };
 
@@ -285,13 +288,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const int wr = wave / WN, wc = wave % WN;
     const int r32 = lane & 31, half = lane >> 5;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
+    int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
+    int vb = blockIdx.x, ks = 0;
+    int64_t kbase = 0;                                          // byte offset of this workgroup's first K-tile
+    if (p.ksplit > 1) {                                         // split-K: workgroup (tile vb, split ks) reduces K-tiles [t0, t0 + nt)
+        ks = vb / nwg;
+        vb -= ks * nwg;
+        const int per = (nt + p.ksplit - 1) / p.ksplit, t0 = min(ks * per, nt);
+        nt = min(per, nt - t0);
+        kbase = (int64_t)t0 * KT_BYTES;
+    }
 
     // ---- direct-to-LDS staging: lane fills physical slot (chunk&7) of row (chunk>>3) with logical slot^f(row) ----
     // SRSRC buffer loads (workgroup-uniform base = first row of the tile, 32-bit lane offsets, K-tile offset in an SGPR):
     // no per-load address VALU, and they issue 2-3x faster than global_load_lds with 64-bit lane addresses.
     int m0, n0;
-    tile_origin(blockIdx.x, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
+    tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
     const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
     const char* a_base = p.A + a_row0 * p.lda_b;            // resources are rebuilt from these at each use (loop-invariant SGPRs)
     const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
@@ -321,9 +333,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const uint32_t c0 = (uint32_t)((half ^ sw) << 4);
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
 
-    {                                                           // K-tile 0
+    if (nt > 0) {                                               // K-tile 0
         char* dst0 = smem + wave * 1024;
-        static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst0, 0); });
+        static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst0, kbase); });
     }
 
     {
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
         for (int t = 0; t < nt; ++t) {
             __syncthreads();                 // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free again
             const bool more = t + 1 < nt;
-            const int64_t ko = (int64_t)(t + 1) * KT_BYTES;
+            const int64_t ko = kbase + (int64_t)(t + 1) * KT_BYTES;
             if constexpr (sizeof(T) == 2) {
                 char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
                 const uint32_t so = lds0 + (t & 1) * STAGE_BYTES;
@@ -377,7 +389,39 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
             }
         }
 
-        gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
+        if (p.ksplit > 1) {
+            GemmParams pe = p;
+            pe.C = reinterpret_cast<OutT*>(p.C) + ks * p.split_stride;
+            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(pe, acc, m0, n0, wr, wc, r32, half, vec_ok);
+        } else {
+            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
+        }
+    }
+}
+
+// out = act(sum_s partial[s] + bias) + resid for the split-K remainder launch (fixed summation order: deterministic)
+template <typename OutT, int ACT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t stride, int M, int N,
+                                                            const float* __restrict__ bias, const float* resid, int64_t ldr,
+                                                            OutT* C, int64_t ldc) {
+    const int n4 = N / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)M * n4) return;
+    const int row = (int)(i / n4), col = (int)(i % n4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)row * N + col);
+    for (int s = 1; s < S; ++s) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(part + s * stride + (int64_t)row * N + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (bias != nullptr) v[e] += bias[col + e];
+        if constexpr (ACT == SPRC_ACT_GELU) v[e] = gelu_fast(v[e]);
+        if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
+        if (resid != nullptr) v[e] += resid[(int64_t)row * ldr + col + e];
+        if constexpr (sizeof(OutT) == 2) C[(int64_t)row * ldc + col + e] = (__bf16)v[e];
+        else C[(int64_t)row * ldc + col + e] = v[e];
     }
 }
 
@@ -605,7 +649,7 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     static const int order = env_int("SPRC_GEMM_ORDER", 0);     // 8-m grouped order is better for the K-heavy 128x128 GEMMs
     p.order = order;
     const int nwg = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(nwg), dim3(64 * WM * WN), LDS, st, p);
+    hipLaunchKernelGGL(kern, dim3(nwg * (p.ksplit > 1 ? p.ksplit : 1)), dim3(64 * WM * WN), LDS, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm");
     return SPRC_OK;
 }
@@ -678,6 +722,23 @@ static int launch(const GemmParams& p, hipStream_t st) {
                 if (p.resid != nullptr) pt.resid = p.resid + (int64_t)Mm * p.ldr;
                 const int rc = launch_anti<OutT, ACT, MAX32>(pm, st);
                 if (rc != SPRC_OK) return rc;
+                // remainder rows: a long reduction on a handful of workgroups is latency-bound (11 WGs x 96 K-tiles = 77 us
+                // for the ViT fc2) -> split K over 8 workgroups per tile into caller scratch and reduce in a fixed order
+                constexpr int S = 8;
+                if (p.K >= 4096 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.scratch != nullptr &&
+                    p.scratch_elems >= (int64_t)S * rem * p.N) {
+                    GemmParams ps = pt;
+                    ps.C = p.scratch; ps.ldc = p.N; ps.bias = nullptr; ps.resid = nullptr; ps.ldr = 0;
+                    ps.ksplit = S; ps.split_stride = (int64_t)rem * p.N;
+                    const int rs = launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 2>(ps, st);
+                    if (rs != SPRC_OK) return rs;
+                    const int64_t n = (int64_t)rem * (p.N / 4);
+                    hipLaunchKernelGGL((splitk_reduce_kernel<OutT, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                       p.scratch, S, ps.split_stride, rem, p.N, p.bias, pt.resid, p.ldr,
+                                       reinterpret_cast<OutT*>(pt.C), p.ldc);
+                    SPRC_CHECK_LAUNCH("sprc_gemm(split-K reduce)");
+                    return SPRC_OK;
+                }
                 return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(pt, st);
             }
             cfg = cB <= cA ? 4 : 2;
@@ -743,6 +804,8 @@ extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) {
         return SPRC_EUNSUPPORTED;
     }
     p.tiles_m = p.tiles_n = 0;
+    p.ksplit = 1; p.split_stride = 0;
+    p.scratch = reinterpret_cast<float*>(a->scratch); p.scratch_elems = (int64_t)(a->scratch_bytes / 4);
     static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
     p.debug = dbg;
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides

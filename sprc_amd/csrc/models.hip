@@ -25,7 +25,7 @@ static const sprc_rowmap ID_MAP = {0, 0, 0};
 
 static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
                 void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0,
-                sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP) {
+                sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0) {
     sprc_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
@@ -33,6 +33,7 @@ static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const v
     g.W = w.w; g.ldw = K; g.bias = w.b;
     g.resid = resid; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.cmap = cmap;
+    g.scratch = scratch; g.scratch_bytes = scratch_bytes;
     return sprc_gemm(&g, st);
 }
 
@@ -208,6 +209,7 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     hipStream_t st = (hipStream_t)s;
     const int dt = m->dtype, D = m->width, T = m->tokens, M = B * T, P = B * (T - 1), F = m->mlp;
     const size_t es = dtype_size(dt);
+    const size_t pout_bytes = (size_t)P * D * 4;
     const float scale = 1.0f / sqrtf((float)m->head_dim);                       // eva_vit.py:74
     RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, dt, st));
     RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D));
@@ -222,7 +224,8 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
         RUN(gemm(st, dt, SPRC_F32, M, D, D, v.ctx, D, L.proj, v.x, D, SPRC_ACT_NONE, v.x, D));
         RUN(lnorm(st, dt, M, D, v.x, L.ln2_w, L.ln2_b, m->ln_eps, nullptr, v.h));
         RUN(gemm(st, dt, dt, M, F, D, v.h, D, L.fc1, v.mlp, F, m->act));
-        RUN(gemm(st, dt, SPRC_F32, M, D, F, v.mlp, F, L.fc2, v.x, D, SPRC_ACT_NONE, v.x, D));
+        // split-K scratch for the remainder rows of the K = mlp product: the patch-embedding output buffer is dead by now
+        RUN(gemm(st, dt, SPRC_F32, M, D, F, v.mlp, F, L.fc2, v.x, D, SPRC_ACT_NONE, v.x, D, ID_MAP, ID_MAP, v.pout, pout_bytes));
     }
     RUN(lnorm(st, dt, M, D, v.x, m->ln_vision_w, m->ln_vision_b, m->ln_vision_eps, raw, nullptr));
     return SPRC_OK;

@@ -33,7 +33,7 @@ def rowmap(rows_per_group: int = 0, group_stride: int = 0, group_offset: int = 0
 # thin operator wrappers (used by the unit parity tests and by Engine)
 # --------------------------------------------------------------------------------------------
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None, act=L.ACT_NONE, out=None,
-         M=None, amap=None, cmap=None, ldc=None) -> torch.Tensor:
+         M=None, amap=None, cmap=None, ldc=None, scratch=None) -> torch.Tensor:
     lib = L.load()
     dt = L.SPRC_BF16 if A.dtype == torch.bfloat16 else L.SPRC_F32
     assert W.dtype == A.dtype and A.is_cuda and A.stride(-1) == 1 and W.stride(-1) == 1
@@ -49,6 +49,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None
     g.bias = _ptr(bias)
     g.resid, g.ldr = _ptr(resid), (resid.stride(0) if resid is not None else 0)
     g.C, g.ldc, g.cmap = out.data_ptr(), (out.stride(0) if ldc is None else ldc), cmap or rowmap()
+    if scratch is not None:                      # optional split-K scratch (include/sprc.h)
+        g.scratch, g.scratch_bytes = scratch.data_ptr(), scratch.numel() * scratch.element_size()
     L.check(lib.sprc_gemm(C.byref(g), _stream()), "sprc_gemm")
     return out
 

@@ -59,6 +59,29 @@ def test_gemm_bf16_256_tile_and_peel(M, N, K):
         assert torch.equal(again, out)
 
 
+@pytest.mark.parametrize("odt,act", [(L.SPRC_F32, L.ACT_NONE), (L.SPRC_BF16, L.ACT_GELU)])
+def test_gemm_bf16_splitk_remainder(odt, act):
+    """K >= 4096 with caller scratch: the remainder rows of the peeled split are reduced by 8 workgroups per tile (fixed
+    summation order); same result contract as the plain launch, and bit-stable across launches."""
+    M, N, K = 4096 + 100, 4096, 4096
+    A, W, b, r = _bf(_rand((M, K), 31)), _bf(_rand((N, K), 32, 0.03)), _rand((N,), 33), _rand((M, N), 34)
+    z = A.double() @ W.double().t() + b.double()
+    if act == L.ACT_GELU:
+        z = torch.nn.functional.gelu(z)
+    ref = z + r.double()
+    scratch = torch.empty(8 * 128 * N, dtype=torch.float32, device=DEV)
+    out = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), resid=r.to(DEV), out_dtype=odt, act=act, scratch=scratch).cpu()
+    plain = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), resid=r.to(DEV), out_dtype=odt, act=act).cpu()
+    if odt == L.SPRC_F32:
+        torch.testing.assert_close(out.double(), ref, atol=2e-3 * math.sqrt(K / 64), rtol=1e-4)
+        torch.testing.assert_close(out, plain, atol=1e-4, rtol=1e-5)          # only the summation order differs
+        assert torch.equal(out[:4096], plain[:4096])                            # main rows: same kernel, same bits
+    else:
+        torch.testing.assert_close(out.float(), ref.float().to(torch.bfloat16).float(), atol=3e-2, rtol=2e-2)
+    again = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), resid=r.to(DEV), out_dtype=odt, act=act, scratch=scratch).cpu()
+    assert torch.equal(again, out)
+
+
 @pytest.mark.parametrize("M,N,K", [(257, 1408, 1408), (70, 96, 32), (130, 256, 768), (33, 128, 608)])
 def test_gemm_f32(M, N, K):
     A, W, b = _rand((M, K), 4), _rand((N, K), 5, 0.05), _rand((N,), 6)
