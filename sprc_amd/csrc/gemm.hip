@@ -3,23 +3,24 @@
 // Replaces every nn.Linear / F.linear / conv-as-GEMM on the SPRC retrieval path (see sprc.h).
 // Both operands are K-contiguous ("B^T" form), so A and W fragments are read the same way.
 //
-// One kernel template, two tile configurations (workgroup tile BM x BN, K-tile = 128 bytes of K):
-//   256 x 256, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA 32x32 accumulators, 1 WG / CU   (large GEMMs)
-//   128 x 128, 4 waves (2 x 2), wave tile  64 x 64 = 2 x 2,                         2 WGs / CU  (small GEMMs)
+// Two kernels (workgroup tile BM x BN, K-tile = 128 bytes of K):
+//   gemm_anti_kernel  256 x 256, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA 32x32 accumulators, 1 WG / CU, bf16:
+//                     two wave groups in anti-phase (one in a 16-MFMA cluster while the other reads fragments and
+//                     stages), piece-scheduled staging with counted vmcnt -- see the comment above the kernel
+//   gemm_kernel       128 x 128, 4 waves (2 x 2), wave tile 64 x 64, 2 WGs / CU (small grids, remainder rows, split-K,
+//                     and every fp32 GEMM; also instantiated as a lock-step 256 x 256 for the fp32 engine)
 //     bf16: v_mfma_f32_32x32x16_bf16, K-tile = 64 elements;  f32: v_mfma_f32_32x32x2_f32 (exact fp32), 32 elements
-// Why big tiles: a CU's vector-memory path delivers ~64 B/clk; a 128x128x64 tile needs 32 KiB per 512 MFMA-cycles
-// = 64 B/clk at peak MFMA rate (measured 517-635 TFLOP/s, memory-path bound); a 256x256 tile needs half of that.
-// Data movement: K-tiles go HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR
-// round trip), double buffered.  The LDS image of a wave-instruction is lane-linear (8 rows x 8 16-B slots), so the
-// XOR swizzle (slot ^= (row>>1)&7: every ds_read_b128 lane group hits 16 distinct slots of the 256-B bank row,
-// SQ_LDS_BANK_CONFLICT = 0) is applied to the per-lane SOURCE address and to the fragment reads, never to the
-// destination (guide rule 21).
-// bf16 main loop is hand software-pipelined (inline-asm ds_read_b128 + counted lgkmcnt): fragment reads of k-step
-// kk+1 and a quarter of the next K-tile's global->LDS loads are issued before the MFMAs of k-step kk.
-// The kernel body is a tile loop (optional persistent mode: grid = CUs x residency, next tile's K-tile 0 prefetched
-// before the epilogue); measured no gain over one workgroup per tile, which is what is launched.
-// Tile order: XCD-contiguous remap of vb (block b runs on XCD b%8) + 8-row grouped order, so tiles resident on one
-// XCD share A/W panels in its L2.
+// The dispatcher (launch<>) chooses between them -- and a "256x256 on the first M & ~255 rows + 128x128 on the rest"
+// split -- with a round-count cost model.
+// Data movement: K-tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds through an SRSRC based at the tile's
+// first row: 1 KiB per wave-instruction, no VGPR round trip, no per-load address arithmetic), double buffered.  The LDS
+// image of a wave-instruction is lane-linear (8 rows x 8 16-B slots), so the XOR swizzle (slot ^= (row>>1)&7: every
+// ds_read_b128 lane group hits 16 distinct slots of the 256-B bank row, SQ_LDS_BANK_CONFLICT = 0) is applied to the
+// per-lane SOURCE offset and to the fragment reads, never to the destination (guide rule 21).
+// The 128x128 bf16 main loop is hand software-pipelined (inline-asm ds_read_b128 + counted lgkmcnt): fragment reads of
+// k-step kk+1 and a quarter of the next K-tile's loads are issued before the MFMAs of k-step kk.
+// Tile order: XCD-contiguous remap of the block index (block b runs on XCD b%8) + grouped order, so tiles resident on
+// one XCD share A/W panels in its L2.
 // Epilogue: MFMAs compute the TRANSPOSED tile, so a lane owns one C row and 4 consecutive columns per register
 // quad: bias / residual / output are 16-B (fp32) or 8-B (bf16) vectors.
 #include <stdlib.h>
@@ -442,9 +443,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Staging (measured with s_memtime, tools/gemm_stamp.py: an NC interval carrying 12 ds_read_b128 + 4 global->LDS loads takes
 // 500-700 cycles to ISSUE against a 560-cycle cluster, and draining to vmcnt(0) costs up to 500 more): the K-tile is cut
 // into eight 8-KB pieces (64 rows x 128 B: A0..A3, B0..B3; group g reads A(2g), A(2g+1) and every B), two loads per thread
-// per piece, TWO pieces per NC interval and group (as SRSRC buffer loads: a global_load_lds with its 64-bit lane
-// addresses took 2-3x longer to issue), none inside the clusters, and every wait is a counted vmcnt(4) that leaves the
-// newest two pieces in flight:
+// per piece, TWO pieces per interval pair and group (as SRSRC buffer loads: a global_load_lds with its 64-bit lane
+// addresses took 2-3x longer to issue) -- three loads in the NC interval, the fourth inside the following cluster -- and
+// every wait is a counted vmcnt(3/4) that leaves the newest pieces in flight:
 //   interval     4t-1            4t              4t+1            4t+2            4t+3
 //   issues       G1: A0 A1(t+1)  G0: B0 B1(t+1)  G1: B2 B3(t+1)  G0: A2 A3(t+1)  G1: A0 A1(t+2)
 //   first read of tile t+1: A0 A1 B* in 4t+4 (G0), A2 A3 in 4t+5 (G1); last read of tile t-1: A0 A1 in 4t-2, rest in 4t-1.
@@ -523,12 +524,14 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(bn); });
         });
     };
-    auto cluster = [&]() {                                  // 16 MFMAs: k-steps 2h, 2h+1 of the 128 x 64 wave tile
+    // 16 MFMAs: k-steps 2h, 2h+1 of the 128 x 64 wave tile; when `tile` >= 0 the SECOND load of piece q goes out mid-cluster
+    auto cluster = [&](auto q_, int tile) {
         __builtin_amdgcn_s_setprio(1);
         static_for<0, 16>([&](auto x_) {
             constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[k][ni]),
                                                                   __builtin_bit_cast(bf16x8, fa[k][mi]), acc[mi][ni], 0, 0, 0);
+            if constexpr (x == 7) { if (tile >= 0) load_piece(q_, I1{}, tile); }
         });
         __builtin_amdgcn_s_setprio(0);
     };
@@ -557,12 +560,15 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     barrier();
     if (wr == 1) barrier();
     const bool dbg_noload = p.debug & 1, dbg_noread = p.debug & 2;
+    // 3 of an interval pair's 4 loads go out in the NC interval, the 4th after the 8th MFMA of the following cluster:
+    // NC (12 fragment reads + loads, ~600 cycles) was longer than the cluster (~530); A/B +2 % (debug bit 512 = all 4 in NC)
+    const bool split31 = !(p.debug & 512);
     if (dbg_noread) { reads(0, 0); wait_lgkmcnt<0>(); }
     // STAMP build (tools only): s_memtime at the phase boundaries of K-tile 8, written over p.resid by waves 0 and 4 of WG 0
     uint64_t ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](auto i_, int t) {
         if constexpr (STAMP) {
-            if (t == 8) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();
+            if (t == 8 && ((p.ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
         }
     };
     for (int t = 0; t < nt; ++t) {
@@ -571,26 +577,30 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         const bool has_p2 = wr ? n2 : n1;
         stamp(integral_constant<int, 0>{}, t);
         if (!dbg_noread) reads(t, 0);                       // NC(t,0)
-        if (n1) { piece(I0{}, t + 1); piece(I1{}, t + 1); }
+        if (n1) { piece(I0{}, t + 1); load_piece(I1{}, I0{}, t + 1); if (!split31) load_piece(I1{}, I1{}, t + 1); }
         stamp(integral_constant<int, 1>{}, t);
         wait_lgkmcnt<0>();
-        if (wr == 0) wait_vm(n1);                           // A2 A3 of t landed (G1 reads them in the next interval)
+        if (wr == 0) {                                      // A2 A3 of t landed (G1 reads them in the next interval)
+            if (split31 && n1) wait_vmcnt<3>(); else wait_vm(n1);
+        }
         stamp(integral_constant<int, 2>{}, t);
         barrier();
         stamp(integral_constant<int, 3>{}, t);
-        cluster();                                          // C(t,0)
+        cluster(I1{}, split31 && n1 ? t + 1 : -1);          // C(t,0)
         stamp(integral_constant<int, 4>{}, t);
         barrier();
         stamp(integral_constant<int, 5>{}, t);
         if (!dbg_noread) reads(t, 1);                       // NC(t,1)
-        if (has_p2) { piece(I2{}, t_p2); piece(I3{}, t_p2); }
+        if (has_p2) { piece(I2{}, t_p2); load_piece(I3{}, I0{}, t_p2); if (!split31) load_piece(I3{}, I1{}, t_p2); }
         stamp(integral_constant<int, 6>{}, t);
         wait_lgkmcnt<0>();
-        if (wr == 1) wait_vm(n2);                           // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
+        if (wr == 1) {                                      // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
+            if (split31 && n2) wait_vmcnt<3>(); else wait_vm(n2);
+        }
         stamp(integral_constant<int, 7>{}, t);
         barrier();
         stamp(integral_constant<int, 8>{}, t);
-        cluster();                                          // C(t,1)
+        cluster(I3{}, split31 && has_p2 ? t_p2 : -1);       // C(t,1)
         stamp(integral_constant<int, 9>{}, t);
         if (wr == 0) wait_vm(n1);                           // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
         stamp(integral_constant<int, 10>{}, t);
@@ -619,7 +629,7 @@ static int ilog2_exact(int v) {
 // SPRC_GEMM_TILE: 0 = automatic (default), 2 = 128x128, 4 = 256x256
 static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
+    return e ? (int)strtol(e, nullptr, 0) : dflt;
 }
 static int num_cus() {
     static int n = 0;
@@ -665,6 +675,7 @@ static int launch_anti(GemmParams p, hipStream_t st) {
             p.tiles_m = (p.M + 255) / 256;
             p.tiles_n = (p.N + 255) / 256;
             p.order = 4;
+            p.ksplit = env_int("SPRC_GEMM_STAMP_MASK", 0xfff);
             hipLaunchKernelGGL(sk, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS, st, p);
             SPRC_CHECK_LAUNCH("sprc_gemm(anti, stamp)");
             return SPRC_OK;
