@@ -11,6 +11,7 @@ Files written:
   tests/golden/tiny_eva.npz    ViT-g width, depth 2, 12-layer Q-Former : every stage boundary
   tests/golden/tiny_clip.npz   ViT-L width, depth 2                    : every stage boundary
   tests/golden/full_eva.npz    full depth (39 blocks), 2 images, 3 queries   (--full, ~3 min)
+  tests/golden/full_clip.npz   full depth ViT-L (23 blocks), 2 images, 3 queries   (--full)
   tests/golden/metrics.json    reference compute_cirr_val_metrics / compute_fiq_val_metrics /
                                generate_cirr_test_dicts on synthetic sims (with engineered ties)
   tests/golden/captions.json   reference BlipCaptionProcessor + FashionIQ caption composition
@@ -223,6 +224,8 @@ def main():
         model_goldens("pretrain_vitL", 2, n_img=3, n_q=4, out=GOLD / "tiny_clip.npz")
     if a.full and want("full_eva"):
         model_goldens("pretrain", None, n_img=2, n_q=3, out=GOLD / "full_eva.npz")
+    if a.full and want("full_clip"):
+        model_goldens("pretrain_vitL", None, n_img=2, n_q=3, out=GOLD / "full_clip.npz")
 
 
 if __name__ == "__main__":

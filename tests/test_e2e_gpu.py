@@ -39,7 +39,7 @@ def _run(g, eng, images):
     return raw.cpu().numpy(), feats.cpu().numpy(), fusion.cpu().numpy(), sim.cpu().numpy()
 
 
-@pytest.mark.parametrize("name", ["tiny_eva.npz", "tiny_clip.npz", "full_eva.npz"])
+@pytest.mark.parametrize("name", ["tiny_eva.npz", "tiny_clip.npz", "full_eva.npz", "full_clip.npz"])
 def test_fp32_engine_matches_reference(golden_dir, name):
     g, cfg, eng, images = _setup(golden_dir, name, "fp32")
     raw, feats, fusion, sim = _run(g, eng, images)
@@ -54,7 +54,7 @@ def test_fp32_engine_matches_reference(golden_dir, name):
           f"max|draw|={np.abs(raw[:, rows] - g['raw']).max():.2e}")
 
 
-@pytest.mark.parametrize("name", ["tiny_eva.npz", "tiny_clip.npz", "full_eva.npz"])
+@pytest.mark.parametrize("name", ["tiny_eva.npz", "tiny_clip.npz", "full_eva.npz", "full_clip.npz"])
 def test_bf16_engine_within_tolerance(golden_dir, name):
     g, cfg, eng, images = _setup(golden_dir, name, "bf16")
     raw, feats, fusion, sim = _run(g, eng, images)
@@ -65,7 +65,7 @@ def test_bf16_engine_within_tolerance(golden_dir, name):
     print(f"\n[{name} bf16] max|dsim|={dsim:.2e} min cos(feats)={cos_feats:.6f} min cos(fusion)={cos_fusion:.6f} "
           f"max|draw|={np.abs(raw[:, rows] - g['raw']).max():.2e}")
     assert cos_feats > 0.995 and cos_fusion > 0.995
-    assert dsim < 5e-3        # north-star asks 1e-3 vs the fp32 CPU path; see DESIGN.md "numerics" for the measured value
+    assert dsim < 1e-3        # the north star's tolerance: cosine scores within 1e-3 of the fp32 CPU path (measured 4e-4 .. 8e-4)
 
 
 def test_ranking_is_bit_exact_on_device_scores(golden_dir):

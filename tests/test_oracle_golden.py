@@ -60,11 +60,12 @@ def test_model_stages_match_reference(golden_dir, name):
 
 
 @pytest.mark.slow
-def test_full_depth_matches_reference(golden_dir):
-    path = golden_dir / "full_eva.npz"
+@pytest.mark.parametrize("name", ["full_eva.npz", "full_clip.npz"])
+def test_full_depth_matches_reference(golden_dir, name):
+    path = golden_dir / name
     if not path.exists():
         pytest.skip("full-depth golden not generated")
-    g, cfg, sd, images = _load(golden_dir, "full_eva.npz")
+    g, cfg, sd, images = _load(golden_dir, name)
     with torch.no_grad():
         feats, raw = O.extract_target_features(sd, cfg, images)
         sim = O.inference(sd, cfg, raw[torch.from_numpy(g["ref_index"])], feats,
