@@ -174,21 +174,70 @@ __device__ __forceinline__ void tile_origin(int vb, int nwg, int tiles_m, int ti
 }
 
 // ---- epilogue (shared).  Transposed 32x32 D layout: m = rbase + (lane&31),  n = cbase + 8*(r>>2) + 4*(lane>>5) + (r&3) ----
+// Each wave transposes its accumulators through a private LDS strip (32 rows x (32 TN + 4) floats: the padding makes both
+// the ds_write_b128 of the fragment layout and the row-major ds_read_b128 conflict-free) so that global memory sees FULL
+// cache lines: one wave instruction covers 64/(8 TN) whole rows x 128 TN bytes.  With the fragment layout written straight
+// out, an instruction touched 32 rows x 32 B and a 256 x 256 fp32 tile with residual took ~55k cycles (7 B/clk/CU,
+// store-issue bound: s_memtime, tools/gemm_stamp.py) -- more than a third of a K = 1408 tile.
+// The caller guarantees every wave is done reading operand tiles from LDS (a barrier after the K loop).
+constexpr int EPI_STRIP_BYTES(int TN) { return 32 * (32 * TN + 4) * 4; }
+
 template <typename T, typename OutT, int ACT, bool MAX32, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int cm0, int cn0, int wr, int wc,
-                                              int r32, int half, bool vec_ok) {
-    // bias of this lane's 4-column groups: loaded ONCE, before any of it is needed (it used to be one load + vmcnt(0) round
-    // trip per group and row block: 32 serial L2 latencies per thread)
-    f32x4 bv[TN][4];
+                                              int r32, int half, bool vec_ok, char* smem, int wave) {
     if constexpr (!MAX32) {
         if (vec_ok) {
+            constexpr int CH = 8 * TN, RPI = 64 / CH, ITERS = 32 / RPI, LD = (32 * TN + 4) * 4;   // 16-B chunks per row, rows per instruction
+            const int lane = half * 32 + r32, ch = lane % CH, rsub = lane / CH;
+            char* strip = smem + wave * EPI_STRIP_BYTES(TN);
+            const int col = cn0 + wc * TN * 32 + ch * 4;
+            const bool col_ok = col < p.N;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
+            for (int mi = 0; mi < TM; ++mi) {
+                // residual rows of this block first (C may alias it: every element is read by the lane that writes it)
+                f32x4 rv[ITERS];
+                int64_t prow[ITERS];
+                bool ok[ITERS];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = cn0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
-                    bv[ni][g] = (p.bias != nullptr && col < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int it = 0; it < ITERS; ++it) {
+                    const int row = cm0 + (wr * TM + mi) * 32 + it * RPI + rsub;
+                    ok[it] = row < p.M && col_ok;
+                    prow[it] = map_row_s(p.c_shift, p.c_stride, p.c_off, row < p.M ? row : 0);
+                    rv[it] = (p.resid != nullptr && ok[it]) ? *reinterpret_cast<const f32x4*>(p.resid + prow[it] * p.ldr + col)
+                                                           : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(strip + r32 * LD + (ni * 32 + 8 * g + 4 * half) * 4) =
+                            f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + rsub) * LD + ch * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {           // element-wise on purpose: vector adds become v_pk_add_f32 (slower)
+                        v[e] += bv[e];
+                        if constexpr (ACT == SPRC_ACT_GELU) {
+                            if constexpr (sizeof(T) == 2) v[e] = gelu_fast(v[e]);
+                            else v[e] = gelu_erf(v[e]);
+                        }
+                        if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
+                        v[e] += rv[it][e];
+                    }
+                    if (!ok[it]) continue;
+                    OutT* dst = reinterpret_cast<OutT*>(p.C) + prow[it] * p.ldc + col;
+                    if constexpr (sizeof(OutT) == 2) {
+                        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+                        *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+            }
+            return;
         }
     }
 #pragma unroll
@@ -211,49 +260,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, row_ok ? row : 0);
             const float* rrow = p.resid ? p.resid + prow * p.ldr : nullptr;
             OutT* crow = reinterpret_cast<OutT*>(p.C) + prow * p.ldc;
-            if (vec_ok) {
-                f32x4 rv[TN][4];
-                if (rrow != nullptr) {                // gather the residual first (C may alias it: in-place stream)
-#pragma unroll
-                    for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int col = cn0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
-                            rv[ni][g] = (row_ok && col < p.N) ? *reinterpret_cast<const f32x4*>(rrow + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                }
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int col = cn0 + (wc * TN + ni) * 32 + 8 * g + 4 * half;
-                        if (!(row_ok && col < p.N)) continue;
-                        f32x4 v = {acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += bv[ni][g][e];      // element-wise on purpose: a vector add becomes v_pk_add_f32 (slower)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if constexpr (ACT == SPRC_ACT_GELU) {
-                                if constexpr (sizeof(T) == 2) v[e] = gelu_fast(v[e]);
-                                else v[e] = gelu_erf(v[e]);
-                            }
-                            if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
-                        }
-                        if (rrow != nullptr) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += rv[ni][g][e];
-                        }
-                        if constexpr (sizeof(OutT) == 2) {
-                            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                            if (p.debug & 4) __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(crow + col));
-                            else *reinterpret_cast<bf16x4*>(crow + col) = o;
-                        } else {
-                            if (p.debug & 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(crow + col));
-                            else *reinterpret_cast<f32x4*>(crow + col) = v;
-                        }
-                    }
-            } else {                                  // unaligned / ragged N: scalar path
+            {                                         // unaligned / ragged N: scalar path (the vector path returned above)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -390,12 +397,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
             }
         }
 
+        __syncthreads();                     // every wave is done reading operand tiles: the epilogue reuses LDS
         if (p.ksplit > 1) {
             GemmParams pe = p;
             pe.C = reinterpret_cast<OutT*>(p.C) + ks * p.split_stride;
-            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(pe, acc, m0, n0, wr, wc, r32, half, vec_ok);
+            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(pe, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
         } else {
-            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
+            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
         }
     }
 }
@@ -464,6 +472,8 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     const int r32 = lane & 31, half = lane >> 5;
     const int nwg = p.tiles_m * p.tiles_n;
     const int nt = p.K / 64;
+    uint64_t tile_ts[4] = {0, 0, 0, 0};                      // STAMP build: entry | prologue done | K loop done | epilogue done
+    if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
 
     int m0, n0;
     tile_origin(blockIdx.x, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     else wait_vmcnt<0>();
     barrier();
     if (wr == 1) barrier();
+    if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
     const bool dbg_noload = p.debug & 1, dbg_noread = p.debug & 2;
     // 3 of an interval pair's 4 loads go out in the NC interval, the 4th after the 8th MFMA of the following cluster:
     // NC (12 fragment reads + loads, ~600 cycles) was longer than the cluster (~530); A/B +2 % (debug bit 512 = all 4 in NC)
@@ -608,13 +619,22 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         stamp(integral_constant<int, 11>{}, t);
     }
     if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
+    if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
-    gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok);
+    gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
     if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's stores have left the wave
+        tile_ts[3] = __builtin_amdgcn_s_memtime();
         if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) {
             uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + (wave >> 2) * 16;
 #pragma unroll
             for (int i = 0; i < 12; ++i) o[i] = ts[i];
+        }
+        // whole-tile timeline of a third-round workgroup (steady state): slots 32.. of the resid buffer
+        if (blockIdx.x == 2 * 256 + 40 && lane == 0 && (wave & 3) == 0) {
+            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + 32 + (wave >> 2) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = tile_ts[i];
         }
     }
 }

@@ -24,3 +24,7 @@ for rep in range(3):
         t = ts[g * 16:g * 16 + 12]
         d = "  ".join(f"{a}->{b}: {int(t[b] - t[a])}" for a, b in zip(live[:-1], live[1:]))
         print(f"mask {mask:#05x} rep{rep} G{g} :: {d}")
+    tt = R.view(-1)[:128].view(torch.int64).cpu().numpy()[32:40]
+    for g in range(2):
+        t = tt[g * 4:g * 4 + 4]
+        print(f"   tile timeline (WG 552) G{g}: prologue {int(t[1] - t[0])}  K loop {int(t[2] - t[1])}  epilogue {int(t[3] - t[2])}  cycles")
