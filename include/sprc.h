@@ -53,7 +53,11 @@ const char* sprc_last_error(void);
  * (what bench.py's `roofline` leg reads).  enable(1) clears the records; collect() synchronises the
  * recorded events and sums elapsed time, ALGORITHMIC flops and bytes per class. */
 enum { SPRC_K_GEMM_BF16 = 0, SPRC_K_GEMM_F32 = 1, SPRC_K_ATTN = 2, SPRC_K_ROWOPS = 3, SPRC_K_RANK = 4, SPRC_K_COUNT = 5 };
-typedef struct { double ms, flops, bytes; int64_t launches; } sprc_prof_entry;
+typedef struct {
+    double ms, flops, bytes;   /* sum of launch durations; algorithmic flops and bytes */
+    int64_t launches;
+    double busy_ms;            /* union of the launches' [start,end] intervals: == ms unless launches of the class overlapped */
+} sprc_prof_entry;
 int sprc_prof_enable(int on);
 int sprc_prof_collect(sprc_prof_entry* out /* [SPRC_K_COUNT] */);
 

@@ -47,7 +47,7 @@ class QformerEmbedArgs(C.Structure):
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", i64)]
+    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", i64), ("busy_ms", C.c_double)]
 
 
 K_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "rowops", "rank")

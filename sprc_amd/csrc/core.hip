@@ -1,7 +1,9 @@
 // core.hip -- version, error reporting
 #include <stdarg.h>
 
+#include <algorithm>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -57,12 +59,29 @@ extern "C" int sprc_prof_collect(sprc_prof_entry* out) {
     using namespace sprc;
     SPRC_REQUIRE(out != nullptr, "sprc_prof_collect: null output");
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < SPRC_K_COUNT; ++i) out[i] = sprc_prof_entry{0.0, 0.0, 0.0, 0};
+    for (int i = 0; i < SPRC_K_COUNT; ++i) out[i] = sprc_prof_entry{0.0, 0.0, 0.0, 0, 0.0};
+    // launches of one class may overlap in time when the library pipelines two streams: `ms` is the plain sum of launch
+    // durations, `busy_ms` the length of the UNION of their [start, end] intervals (time with >= 1 launch of the class
+    // executing); on a single stream the two agree.
+    std::vector<std::pair<float, float>> iv[SPRC_K_COUNT];
     for (auto& r : g_recs) {
         if (hipEventSynchronize(r.b) != hipSuccess) { set_error("sprc_prof_collect: event sync failed"); return SPRC_ELAUNCH; }
-        float ms = 0.f;
+        float ms = 0.f, t0 = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
+        (void)hipEventElapsedTime(&t0, g_recs.front().a, r.a);
         out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes; out[r.cls].launches += 1;
+        iv[r.cls].push_back({t0, t0 + ms});
+    }
+    for (int c = 0; c < SPRC_K_COUNT; ++c) {
+        std::sort(iv[c].begin(), iv[c].end());
+        float lo = 0.f, hi = 0.f;
+        bool open = false;
+        for (auto& x : iv[c]) {
+            if (open && x.first <= hi) { hi = std::max(hi, x.second); continue; }
+            if (open) out[c].busy_ms += hi - lo;
+            lo = x.first; hi = x.second; open = true;
+        }
+        if (open) out[c].busy_ms += hi - lo;
     }
     return SPRC_OK;
 }
