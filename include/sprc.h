@@ -208,7 +208,9 @@ size_t sprc_vit_workspace_bytes(const sprc_vit_model* m, int32_t B);
 size_t sprc_qformer_workspace_bytes(const sprc_qformer_model* m, int32_t B);
 
 /* raw[B,tokens,width] (fp32) = ln_vision(ViT(images[B,3,S,S]))   -- align_prompt.py:366-368,
- * eva_vit.py:324-340 / clip_vit.py:171-185, blip2.py:193-199. */
+ * eva_vit.py:324-340 / clip_vit.py:171-185, blip2.py:193-199.
+ * Environment SPRC_VIT_STREAMS=2 (read at the first call): the two halves of a batch of >= 16 run the transformer blocks
+ * on `s` and on one library-owned helper stream, forked after and joined before the rest of the work on `s`. */
 int sprc_vit_forward(const sprc_vit_model* m, const float* images, int32_t B, float* raw,
                      void* ws, size_t ws_bytes, sprc_stream s);
 
