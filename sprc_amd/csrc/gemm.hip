@@ -582,8 +582,23 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             if (t == 8 && ((p.ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
         }
     };
+    // Residual prefetch: one throw-away dword load per 128-B line of this wave's 128 x 64 fp32 residual block (4 per lane),
+    // issued in the LAST K-tile -- no staging load is outstanding or issued any more, so its vmcnt waits are dropped --
+    // so that the read half of the epilogue's HBM burst happens under the last MFMAs and the epilogue finds the lines in L2.
+    const bool pf_resid = p.resid != nullptr && !(p.debug & 1024);
+    const float* pf_addr[4];
+    uint32_t pf_sink = 0;
+    if (pf_resid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int line = i * 64 + lane, row = m0 + wr * 128 + (line >> 1), col = n0 + wc * 64 + (line & 1) * 32;
+            const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, min(row, p.M - 1));
+            pf_addr[i] = p.resid + prow * p.ldr + min(col, p.N - 1);
+        }
+    }
     for (int t = 0; t < nt; ++t) {
         const bool n1 = t + 1 < nt && !dbg_noload, n2 = t + 2 < nt && !dbg_noload;
+        const bool last = t + 1 == nt;
         const int t_p2 = wr ? t + 2 : t + 1;                // K-tile of the pieces issued in NC(t,1)
         const bool has_p2 = wr ? n2 : n1;
         stamp(integral_constant<int, 0>{}, t);
@@ -593,6 +608,10 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         wait_lgkmcnt<0>();
         if (wr == 0) {                                      // A2 A3 of t landed (G1 reads them in the next interval)
             if (split31 && n1) wait_vmcnt<3>(); else wait_vm(n1);
+        }
+        if (last && pf_resid) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_addr[i]) : "memory");
         }
         stamp(integral_constant<int, 2>{}, t);
         barrier();
@@ -605,7 +624,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         if (has_p2) { piece(I2{}, t_p2); load_piece(I3{}, I0{}, t_p2); if (!split31) load_piece(I3{}, I1{}, t_p2); }
         stamp(integral_constant<int, 6>{}, t);
         wait_lgkmcnt<0>();
-        if (wr == 1) {                                      // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
+        if (wr == 1 && !(last && pf_resid)) {               // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
             if (split31 && n2) wait_vmcnt<3>(); else wait_vm(n2);
         }
         stamp(integral_constant<int, 7>{}, t);
@@ -613,12 +632,16 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         stamp(integral_constant<int, 8>{}, t);
         cluster(I3{}, split31 && has_p2 ? t_p2 : -1);       // C(t,1)
         stamp(integral_constant<int, 9>{}, t);
-        if (wr == 0) wait_vm(n1);                           // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
+        if (wr == 0 && !(last && pf_resid)) wait_vm(n1);    // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
         stamp(integral_constant<int, 10>{}, t);
         barrier();
         stamp(integral_constant<int, 11>{}, t);
     }
     if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
+    if (pf_resid) {
+        wait_vmcnt<0>();                                    // the throw-away loads have written their register
+        asm volatile("" :: "v"(pf_sink));
+    }
     if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
     gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
