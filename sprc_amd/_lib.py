@@ -126,6 +126,9 @@ def load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise SprcError(f"{LIB_PATH} is missing: the HIP extension is the only compute path "
                         f"(build it with `python -m sprc_amd.build`)")
+    # torch first: it ships its own libamdhip64; were ours loaded before it, the process would hold two HIP runtimes
+    # and our launches would see "no ROCm-capable device" (same SONAME: the loader then reuses torch's copy for us)
+    import torch  # noqa: F401
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is not exported
