@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--backbone", default="pretrain", choices=["pretrain", "pretrain_vitL"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vit-streams", type=int, default=1, help="2 = pipeline the two halves of a batch on two streams inside sprc_vit_forward (+4 %% images/s; per-kernel timings then overlap)")
-    ap.add_argument("--cpu-images", type=int, default=4)
+    ap.add_argument("--cpu-images", type=int, default=32, help="size of the bounded CPU-baseline sample (~15 s of CPU work on 16 cores)")
     return ap.parse_args()
 
 
