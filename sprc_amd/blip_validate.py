@@ -7,12 +7,14 @@ retrieval path on the MI355X HIP engine.  Extra flag: --dtype (bf16 | fp32).
 from __future__ import annotations
 
 import json
+import os
 from argparse import ArgumentParser
 from statistics import geometric_mean, harmonic_mean, mean
 
 import torch
 
 from .harness import compute_cirr_val_metrics, compute_fiq_val_metrics, extract_index_blip_features
+from .index import load_index, save_index
 from .model import load_model_and_preprocess
 
 
@@ -20,6 +22,20 @@ def _device():
     if not torch.cuda.is_available():
         raise SystemExit("sprc_amd needs an MI355X: the HIP kernels are the only compute path")
     return torch.device("cuda")
+
+
+def _gallery(dataset, model, cache, tag, backbone, dtype):
+    """Encoded gallery `((feats, raw), names)`: from the feature store `<cache>/<tag>.safetensors` when it exists, else
+    encoded now (and stored when a cache directory was given).  No reference counterpart: utils.py:46-77 re-encodes."""
+    path = os.path.join(cache, f"{tag}-{backbone}-{dtype}.safetensors") if cache else None
+    if path and os.path.exists(path):
+        (feats, raw), names, meta = load_index(path, device=model.device)
+        print(f"loaded {len(names)} gallery rows from {path} ({meta})")
+        return (feats, raw), names
+    (feats, raw), names = extract_index_blip_features(dataset, model)
+    if path:
+        save_index(path, feats, names, raw=raw, backbone=backbone, compute_dtype=dtype)
+    return (feats, raw), names
 
 
 def _load(blip_model_name, backbone, model_path, dtype):
@@ -32,13 +48,13 @@ def _load(blip_model_name, backbone, model_path, dtype):
     return model, txt
 
 
-def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16"):
+def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16", index_cache=None):
     from .data_utils import CIRRDataset, targetpad_transform
     model, txt = _load(blip_model_name, backbone, blip_model_path, dtype)
     preprocess = targetpad_transform(1.25, 224)
     relative_val = CIRRDataset("val", "relative", preprocess)
     classic_val = CIRRDataset("val", "classic", preprocess)
-    feats, names = extract_index_blip_features(classic_val, model)
+    feats, names = _gallery(classic_val, model, index_cache, "cirr-val", backbone, dtype)
     r = compute_cirr_val_metrics(relative_val, model, feats, names, txt)
     g1, g2, g3, r1, r5, r10, r50 = r
     out = {"group_recall_at1": g1, "group_recall_at2": g2, "group_recall_at3": g3, "recall_at1": r1, "recall_at5": r5,
@@ -48,7 +64,7 @@ def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16")
     return out
 
 
-def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dtype="bf16"):
+def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dtype="bf16", index_cache=None):
     """FashionIQ evaluation (the reference calls this `clip_finetune_fiq`, blip_validate.py:26-98)."""
     from .data_utils import FashionIQDataset, targetpad_transform
     model, txt = _load(blip_model_name, backbone, model_path, dtype)
@@ -56,7 +72,7 @@ def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dt
     preprocess = targetpad_transform(1.25, 224)
     r10s, r50s = [], []
     for d in val_dress_types:
-        feats, names = extract_index_blip_features(FashionIQDataset("val", [d], "classic", preprocess), model)
+        feats, names = _gallery(FashionIQDataset("val", [d], "classic", preprocess), model, index_cache, f"fiq-val-{d}", backbone, dtype)
         r10, r50 = compute_fiq_val_metrics(FashionIQDataset("val", [d], "relative", preprocess), model, feats, names, txt)
         r10s.append(r10)
         r50s.append(r50)
@@ -80,13 +96,14 @@ def main(argv=None):
     p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
     p.add_argument("--model-path", type=str)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--index-cache", default=None, help="directory of gallery feature stores (sprc_amd/index.py): encode once, reuse")
     a = p.parse_args(argv)
     if a.dataset.lower() not in ("fashioniq", "cirr"):
         raise ValueError("Dataset should be either 'CIRR' or 'FashionIQ")
     if a.dataset.lower() == "cirr":
-        blip_validate_cirr(a.blip_model_name, a.backbone, a.model_path, a.dtype)
+        blip_validate_cirr(a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache)
     else:
-        blip_validate_fiq(["dress", "toptee", "shirt"], a.blip_model_name, a.backbone, a.model_path, a.dtype)
+        blip_validate_fiq(["dress", "toptee", "shirt"], a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache)
 
 
 if __name__ == "__main__":

@@ -109,3 +109,18 @@ def test_large_gallery_topk_bit_exact():
     wv, wi = O.topk_stable(s, 64)
     np.testing.assert_array_equal(i.cpu().numpy(), wi.astype(np.int32))
     np.testing.assert_array_equal(v.cpu().numpy(), wv)
+
+
+def test_ranking_from_a_loaded_feature_store_is_bit_identical(scores, tmp_path):
+    """Encode once, store (sprc_amd/index.py), load, rank: same scores and same top-k bits as from the live tensors."""
+    from sprc_amd.index import load_index, save_index
+    fusion, feats, sim = scores
+    names = [f"img-{i:05d}" for i in range(N)]
+    save_index(tmp_path / "g.safetensors", feats, names, backbone="pretrain", compute_dtype="fp32")
+    (f2, _), n2, _ = load_index(tmp_path / "g.safetensors", device=DEV)
+    assert n2 == names
+    sim2 = E.sim_max(fusion.to(DEV), f2)
+    assert torch.equal(sim2, sim)
+    v1, i1 = E.topk(sim, K)
+    v2, i2 = E.topk(sim2, K)
+    assert torch.equal(i1, i2) and torch.equal(v1, v2)

@@ -128,3 +128,29 @@ def test_shard_bounds_and_owner():
             if hi > lo:
                 assert (owner_of(torch.arange(lo, hi), n, w) == r).all()
         assert cover == list(range(n))
+
+
+def test_feature_store_round_trip(tmp_path):
+    """sprc_amd/index.py: a gallery saved and loaded back is the same bits, names keep their row order, and malformed
+    inputs are refused (duplicate names would silently break the name -> row join of the relative datasets)."""
+    import torch
+    from sprc_amd.index import load_index, save_index
+    g = torch.Generator().manual_seed(0)
+    feats = torch.nn.functional.normalize(torch.randn((37, 32, 256), generator=g), dim=-1)
+    raw = torch.randn((37, 257, 64), generator=g)
+    names = [f"dev-{i:04d}-img{(i * 7) % 37}" for i in range(37)]
+    p = tmp_path / "idx" / "cirr-val.safetensors"
+    save_index(p, feats, names, raw=raw, backbone="pretrain", compute_dtype="bf16")
+    (f2, r2), n2, meta = load_index(p)
+    assert torch.equal(f2, feats) and torch.equal(r2, raw) and n2 == names
+    assert meta["backbone"] == "pretrain" and meta["compute_dtype"] == "bf16" and meta["format"] == "sprc-index-1"
+    (f3, r3), n3, _ = load_index(p, with_raw=False)
+    assert r3 is None and torch.equal(f3, feats) and n3 == names
+    save_index(tmp_path / "noraw.safetensors", feats, names)
+    assert load_index(tmp_path / "noraw.safetensors")[0][1] is None
+    with pytest.raises(ValueError, match="unique"):
+        save_index(tmp_path / "dup.safetensors", feats, ["a"] * 37)
+    with pytest.raises(ValueError, match="one entry per"):
+        save_index(tmp_path / "short.safetensors", feats, names[:-1])
+    with pytest.raises(ValueError, match=r"\[N,32,E\]"):
+        save_index(tmp_path / "shape.safetensors", feats[:, :8], names)
