@@ -111,6 +111,41 @@ def test_large_gallery_topk_bit_exact():
     np.testing.assert_array_equal(v.cpu().numpy(), wv)
 
 
+@pytest.mark.parametrize("name,N,K,out32,act,res", [("qkv", 4224, 1408, False, 0, False), ("proj", 1408, 1408, True, 0, True),
+                                                    ("fc1", 6144, 1408, False, 1, False), ("fc2", 1408, 6144, True, 0, True),
+                                                    ("kv_all", 9216, 1408, False, 0, False)])
+def test_vit_gemms_at_bench_size(name, N, K, out32, act, res):
+    """The five big GEMM shapes of one bench step at their real size (M = 128 x 257 rows: many rounds of 256x256 tiles, the
+    peeled remainder, split-K with scratch): sampled rows against float64 on the CPU, every row against a dense GPU
+    product within bf16 rounding, and bit-identical repeats (a staging race shows up as run-to-run differences)."""
+    from sprc_amd import _lib as L
+    M = 128 * 257
+    g = torch.Generator(device=DEV).manual_seed(sum(map(ord, name)))
+    A = torch.randn((M, K), generator=g, device=DEV).to(torch.bfloat16)
+    W = (torch.randn((N, K), generator=g, device=DEV) * 0.03).to(torch.bfloat16)
+    b = torch.randn((N,), generator=g, device=DEV)
+    r = torch.randn((M, N), generator=g, device=DEV) if res else None
+    scratch = torch.empty(8 * 128 * N, dtype=torch.float32, device=DEV)
+    kw = dict(bias=b, resid=r, out_dtype=L.SPRC_F32 if out32 else L.SPRC_BF16, act=act, scratch=scratch)
+    out = E.gemm(A, W, **kw)
+    assert torch.equal(E.gemm(A, W, **kw), out) and torch.equal(E.gemm(A, W, **kw), out)
+    rows = torch.cat([torch.arange(0, M, 523), torch.arange(M - 140, M)])        # spread + the whole remainder panel
+    z = A[rows].cpu().double() @ W.cpu().double().t() + b.cpu().double()
+    if act == 1:
+        z = torch.nn.functional.gelu(z)
+    if res:
+        z = z + r[rows].cpu().double()
+    got = out[rows].cpu().double()
+    tol = 3e-3 * (K / 64) ** 0.5 if out32 else 3e-2
+    torch.testing.assert_close(got, z, atol=tol, rtol=1e-2 if not out32 else 1e-4)
+    dense = A.float() @ W.float().t() + b                                         # every row, coarse: catches a misplaced tile
+    if act == 1:
+        dense = torch.nn.functional.gelu(dense)
+    if res:
+        dense = dense + r
+    assert (out.float() - dense).abs().max().item() < (0.05 if not out32 else 0.02 * (K / 64) ** 0.5)
+
+
 def test_ranking_from_a_loaded_feature_store_is_bit_identical(scores, tmp_path):
     """Encode once, store (sprc_amd/index.py), load, rank: same scores and same top-k bits as from the live tensors."""
     from sprc_amd.index import load_index, save_index
