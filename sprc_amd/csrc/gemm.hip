@@ -45,7 +45,9 @@ struct GemmParams {
     int order;                          // tile order (tile_origin): 0 = 8-m grouped, n > 0 = groups of n n-tiles sweeping m
     int ksplit;                         // > 1: split-K launch of the 128x128 kernel (grid = tiles x ksplit), raw fp32 partials
     int64_t split_stride;               // elements between the partial planes of consecutive K splits
-    int debug;                          // SPRC_GEMM_DEBUG ablations (timing experiments only): 1 = no global->LDS loads, 2 = no LDS reads
+    int debug;                          // SPRC_GEMM_DEBUG, timing experiments on the 256x256 kernel (results are WRONG with 1 / 2):
+                                        //   1 no global->LDS loads   2 no fragment reads   64 s_memtime stamp build (tools/gemm_stamp.py)
+                                        //   512 all four loads of an interval pair in the NC interval   1024 no residual prefetch
 };
 
 __device__ __forceinline__ int64_t map_row_s(int shift, int stride, int off, int r) {
@@ -102,12 +104,6 @@ template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);       // keep the MFMAs below the wait (guide rule 18)
-}
-
-// MFMA with the accumulator pinned in the AGPR half of the register file ("a" constraint).  hipcc left to itself keeps
-// the 128-register accumulator of the 256x256 tile in arch VGPRs.
-__device__ __forceinline__ void mfma_bf16_agpr(f32x16& acc, const u32x4& a, const u32x4& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
 // One K-tile (4 MFMA k-steps) of a wave's TM x TN accumulator block, hand software-pipelined.
@@ -555,13 +551,6 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         asm volatile("" ::: "memory");
     };
 
-    if ((p.debug & 256) && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
-        // experiment: first-round workgroups of every other CU start half a tile late, so that the epilogue (output
-        // write burst) of one half of the chip overlaps the main loop of the other half
-        const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        const uint64_t wait = (uint64_t)nt * 1500;          // shader cycles: ~half of a tile (nt x ~3000 cycles)
-        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
     // flight, G1 one interval behind
     static_for<0, 4>([&](auto q_) { piece(q_, 0); });
