@@ -58,7 +58,8 @@ typedef struct {
     int64_t launches;
     double busy_ms;            /* union of the launches' [start,end] intervals: == ms unless launches of the class overlapped */
 } sprc_prof_entry;
-int sprc_prof_enable(int on);
+int sprc_prof_enable(int on);   /* 1 = start afresh, 0 = pause (records are kept for collect), 2 = resume.  Every recorded
+                                 * launch costs two stream markers (~7 us of pipeline bubble): sample steps, do not record all */
 int sprc_prof_collect(sprc_prof_entry* out /* [SPRC_K_COUNT] */);
 
 /* fp32 -> bf16 (round-to-nearest-even) weight/feature packing. */

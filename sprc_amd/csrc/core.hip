@@ -46,11 +46,13 @@ ProfScope::~ProfScope() {
 }
 }  // namespace sprc
 
-extern "C" int sprc_prof_enable(int on) {
+extern "C" int sprc_prof_enable(int on) {                 // 1 = start afresh, 0 = pause (records kept for collect), 2 = resume
     using namespace sprc;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
-    g_recs.clear();
+    if (on == 1) {
+        for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+        g_recs.clear();
+    }
     g_prof_on = on != 0;
     return SPRC_OK;
 }
