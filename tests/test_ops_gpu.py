@@ -309,3 +309,36 @@ def test_topk_and_rank_of_are_bit_exact(nq, N, k, ties):
     perm = np.stack([rng.permutation(N) for _ in range(nq)]).astype(np.int32)
     _, idx2 = E.topk(torch.from_numpy(np.take_along_axis(sim, perm, axis=1)).to(DEV), k, gidx=torch.from_numpy(perm).to(DEV))
     np.testing.assert_array_equal(idx2.cpu().numpy()[:, :kk], want_idx.astype(np.int32))
+
+
+def test_profiler_start_pause_resume_and_busy_time():
+    """sprc_prof_enable(1 | 0 | 2) = start afresh / pause / resume; collect sums per class: launches, algorithmic flops,
+    the sum of the launch durations and the union of their intervals (equal on one stream, up to event resolution)."""
+    lib = L.load()
+    A, W = _bf(_rand((512, 256), 1)).to(DEV), _bf(_rand((384, 256), 2)).to(DEV)
+    x, g, b = _rand((300, 768), 3).to(DEV), torch.ones(768, device=DEV), torch.zeros(768, device=DEV)
+
+    def collect():
+        torch.cuda.synchronize()
+        prof = (L.ProfEntry * len(L.K_CLASSES))()
+        L.check(lib.sprc_prof_collect(prof), "sprc_prof_collect")
+        return {n: prof[i] for i, n in enumerate(L.K_CLASSES)}
+
+    lib.sprc_prof_enable(1)
+    E.gemm(A, W)
+    E.gemm(A, W)
+    lib.sprc_prof_enable(0)
+    E.gemm(A, W)                                         # not recorded
+    E.layernorm(x, g, b, 1e-5, L.SPRC_BF16)              # not recorded
+    lib.sprc_prof_enable(2)
+    E.gemm(A, W)
+    E.layernorm(x, g, b, 1e-5, L.SPRC_BF16)
+    lib.sprc_prof_enable(0)
+    p = collect()
+    assert p["gemm_bf16"].launches == 3 and p["rowops"].launches == 1 and p["attention"].launches == 0
+    assert p["gemm_bf16"].flops == 3 * 2.0 * 512 * 384 * 256
+    assert 0.0 < p["gemm_bf16"].busy_ms <= p["gemm_bf16"].ms * 1.001 + 1e-3
+    assert p["gemm_bf16"].ms < 50.0                      # three tiny launches: the paused section is not in the sum
+    lib.sprc_prof_enable(1)                              # start afresh drops the old records
+    lib.sprc_prof_enable(0)
+    assert collect()["gemm_bf16"].launches == 0
