@@ -741,21 +741,34 @@ static int launch(const GemmParams& p, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (cfg == 0) {
             // Cost model in units of one 256x256xK tile on a CU (measured on MI355X, tools/gemm_shapes.py):
-            //   B  256x256 anti-phase kernel, one WG per CU:            rounds(M) x 1
-            //   A  128x128 kernel, two co-resident WGs per CU:           rounds of 2 x CUs tiles x 0.7
-            //   C  B on the first M & ~255 rows + A on the remainder:    rounds(M & ~255) x 1 + 0.4
-            // C matters when the last, partial 256-row panel costs a whole extra round: the ViT GEMMs have
-            // M = 128 x 257 = 128.5 panels, so N = 1408 is 774 tiles = 3.02 rounds (fc2: 732 us whole, 562 + 77 us peeled).
+            //   B  256x256 anti-phase kernel, one WG per CU:            rounds x 1
+            //   A  128x128 kernel, two co-resident WGs per CU:           full rounds of 2 x CUs tiles x 0.7, a last round of
+            //                                                            <= CUs tiles (one WG per CU, running alone) 0.42
+            //   C  B on the first Mm rows (Mm a multiple of 256) + A on the M - Mm remaining ones, + 0.08 for the extra launch
+            // C matters when a partial round of 256x256 tiles is nearly empty: the ViT GEMMs have M = 128 x 257 = 128.5 panels,
+            // so N = 1408 is 774 tiles = 3.02 rounds (fc2: 732 us whole, 562 + 77 us peeled); the Q-Former Q|K|V product of
+            // 233 fused queries is 531 tiles = 2.07 rounds (peel three panels: 504 tiles + 90 small ones).
             const int ncu = num_cus();
-            const int64_t tn256 = (p.N + 255) / 256;
-            auto rounds256 = [&](int m) { return (double)((((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
-            const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-            const double cA = 0.7 * (double)((t128 + 2 * ncu - 1) / (2 * ncu));
-            const double cB = rounds256(p.M);
-            const int Mm = p.M & ~255, rem = p.M - Mm;
+            const int64_t tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
+            auto cost256 = [&](int m) { return (double)((((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
+            auto cost128 = [&](int m) {
+                const int64_t t = (int64_t)((m + 127) / 128) * tn128, full = t / (2 * ncu), last = t % (2 * ncu);
+                return 0.7 * (double)full + (last == 0 ? 0.0 : last <= ncu ? 0.42 : 0.7);
+            };
+            const double cA = cost128(p.M), cB = cost256(p.M);
             static const int peel = env_int("SPRC_GEMM_PEEL", 1);
-            const bool can_peel = peel && !MAX32 && rem > 0 && Mm > 0 && p.a_shift < 0 && p.c_shift < 0;
-            const double cC = can_peel ? rounds256(Mm) + 0.4 : 1e30;
+            const bool can_peel = peel && !MAX32 && p.M > 256 && p.a_shift < 0 && p.c_shift < 0;
+            double cC = 1e30;
+            int Mm = 0;
+            if (can_peel) {
+                for (int j = 0; j <= 12; ++j) {                        // peel the partial panel plus j whole ones
+                    const int m = (p.M / 256 - j) * 256;
+                    if (m <= 0 || m == p.M) continue;
+                    const double c = cost256(m) + cost128(p.M - m) + 0.08;
+                    if (c < cC - 1e-9) { cC = c; Mm = m; }
+                }
+            }
+            const int rem = p.M - Mm;
             if (cC < 0.95 * (cA < cB ? cA : cB)) {
                 GemmParams pm = p, pt = p;
                 pm.M = Mm;
@@ -768,7 +781,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
                 // remainder rows: a long reduction on a handful of workgroups is latency-bound (11 WGs x 96 K-tiles = 77 us
                 // for the ViT fc2) -> split K over 8 workgroups per tile into caller scratch and reduce in a fixed order
                 constexpr int S = 8;
-                if (p.K >= 4096 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.scratch != nullptr &&
+                if (rem <= 128 && p.K >= 4096 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.scratch != nullptr &&
                     p.scratch_elems >= (int64_t)S * rem * p.N) {
                     GemmParams ps = pt;
                     ps.C = p.scratch; ps.ldc = p.N; ps.bias = nullptr; ps.resid = nullptr; ps.ldr = 0;
