@@ -750,7 +750,11 @@ static int launch(const GemmParams& p, hipStream_t st) {
             // 233 fused queries is 531 tiles = 2.07 rounds (peel three panels: 504 tiles + 90 small ones).
             const int ncu = num_cus();
             const int64_t tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
-            auto cost256 = [&](int m) { return (double)((((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
+            // a short reduction with an fp32 + residual epilogue spends as long writing out (an HBM burst no other workgroup
+            // on the CU can hide) as in its K loop: +35 % per round (14912 x 768 x 768: 46 us on 256x256, 40 on 128x128;
+            // 32896 x 1024 x 1024: 131 us peeled, 118 on 128x128)
+            const double f256 = (p.K <= 1024 && sizeof(OutT) == 4 && p.resid != nullptr) ? 1.35 : 1.0;
+            auto cost256 = [&](int m) { return f256 * (double)((((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
             auto cost128 = [&](int m) {
                 const int64_t t = (int64_t)((m + 127) / 128) * tn128, full = t / (2 * ncu), last = t % (2 * ncu);
                 return 0.7 * (double)full + (last == 0 ? 0.0 : last <= ncu ? 0.42 : 0.7);
