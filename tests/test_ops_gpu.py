@@ -59,6 +59,42 @@ def test_gemm_bf16_256_tile_and_peel(M, N, K):
         assert torch.equal(again, out)
 
 
+def test_gemm_bf16_random_shapes_through_the_dispatcher():
+    """60 seeded random problems (ragged M and N, N not a multiple of 4 -> scalar epilogue, K = 1..16 K-tiles, every
+    epilogue combination) so that each dispatcher branch -- 128x128, 256x256, peeled splits with 0..12 whole panels,
+    short-K fp32+residual -- is hit with sizes nobody tuned for; float64 reference on the CPU."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        big = case % 3 == 0
+        M = int(rng.integers(2000, 9000)) if big else int(rng.integers(1, 1200))
+        N = int(rng.choice([768, 1024, 1408, 2304, 3072])) if big else int(rng.integers(1, 700))
+        if not big and case % 4 != 1:
+            N = (N + 3) // 4 * 4
+        K = 64 * int(rng.integers(1, 17))
+        out32 = bool(rng.integers(0, 2))
+        act = int(rng.integers(0, 3))
+        use_res, use_bias = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        A, W = _bf(_rand((M, K), 100 + case)), _bf(_rand((N, K), 200 + case, 0.05))
+        b = _rand((N,), 300 + case) if use_bias else None
+        r = _rand((M, N), 400 + case) if use_res else None
+        z = A.double() @ W.double().t()
+        if b is not None:
+            z = z + b.double()
+        if act == L.ACT_GELU:
+            z = torch.nn.functional.gelu(z)
+        elif act == L.ACT_QUICKGELU:
+            z = z * torch.sigmoid(1.702 * z)
+        if r is not None:
+            z = z + r.double()
+        out = E.gemm(A.to(DEV), W.to(DEV), bias=None if b is None else b.to(DEV), resid=None if r is None else r.to(DEV),
+                     out_dtype=L.SPRC_F32 if out32 else L.SPRC_BF16, act=act).cpu()
+        what = f"case {case}: M={M} N={N} K={K} out32={out32} act={act} res={use_res} bias={use_bias}"
+        if out32:
+            torch.testing.assert_close(out.double(), z, atol=3e-3 * math.sqrt(K / 64), rtol=1e-4, msg=lambda m: f"{what}\n{m}")
+        else:
+            torch.testing.assert_close(out.double(), z, atol=4e-2, rtol=1.6e-2, msg=lambda m: f"{what}\n{m}")
+
+
 @pytest.mark.parametrize("odt,act", [(L.SPRC_F32, L.ACT_NONE), (L.SPRC_BF16, L.ACT_GELU)])
 def test_gemm_bf16_splitk_remainder(odt, act):
     """K >= 4096 with caller scratch: the remainder rows of the peeled split are reduced by 8 workgroups per tile (fixed
