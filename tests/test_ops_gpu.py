@@ -236,6 +236,37 @@ def test_attention(dtype, B, H, Tq, Tk, dh, masked):
     torch.testing.assert_close(out.float().double(), ref, atol=tol, rtol=tol)
 
 
+def test_attention_random_shapes():
+    """30 seeded random attention problems per dtype: ragged Tq / Tk (tails of the 32-row tiles, a single query or key),
+    every head size the kernels take, random padding masks (each batch keeps at least one key)."""
+    rng = np.random.default_rng(77)
+    for case in range(30):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        Tq, Tk = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        dh = 8 * int(rng.integers(1, 13))
+        masked = bool(rng.integers(0, 2))
+        D = H * dh
+        for dtype in ("bf16", "f32"):
+            if dtype == "f32" and dh % 4:
+                continue
+            q, k, v = _rand((B, Tq, D), 500 + case), _rand((B, Tk, D), 600 + case), _rand((B, Tk, D), 700 + case)
+            if dtype == "bf16":
+                q, k, v = _bf(q), _bf(k), _bf(v)
+            mask = None
+            if masked:
+                keep = (torch.from_numpy(rng.random((B, Tk))) > 0.3).float()
+                keep[:, int(rng.integers(0, Tk))] = 1.0
+                mask = (1.0 - keep) * -10000.0
+            scale = dh ** -0.5
+            ref = _attn_ref(q.float().view(B, Tq, H, dh).transpose(1, 2), k.float().view(B, Tk, H, dh).transpose(1, 2),
+                            v.float().view(B, Tk, H, dh).transpose(1, 2), scale, mask).transpose(1, 2).reshape(B * Tq, D)
+            out = E.attention(q.to(DEV).view(B * Tq, D), k.to(DEV).view(B * Tk, D), v.to(DEV).view(B * Tk, D), B, H, Tq, Tk,
+                              dh, D, D, D, scale, key_mask=None if mask is None else mask.to(DEV)).cpu()
+            tol = 2e-2 if dtype == "bf16" else 2e-5
+            what = f"case {case} {dtype}: B={B} H={H} Tq={Tq} Tk={Tk} dh={dh} masked={masked}"
+            torch.testing.assert_close(out.float().double(), ref, atol=tol, rtol=tol, msg=lambda m: f"{what}\n{m}")
+
+
 def test_attention_packed_qkv_layout():
     # q/k/v interleaved as [token][3][H][dh] exactly like the ViT qkv GEMM output (eva_vit.py:125)
     B, H, T, dh = 2, 16, 257, 88
@@ -345,6 +376,33 @@ def test_topk_and_rank_of_are_bit_exact(nq, N, k, ties):
     perm = np.stack([rng.permutation(N) for _ in range(nq)]).astype(np.int32)
     _, idx2 = E.topk(torch.from_numpy(np.take_along_axis(sim, perm, axis=1)).to(DEV), k, gidx=torch.from_numpy(perm).to(DEV))
     np.testing.assert_array_equal(idx2.cpu().numpy()[:, :kk], want_idx.astype(np.int32))
+
+
+def test_topk_rank_random_shapes():
+    """40 seeded random ranking problems: any k <= 64, N from 1 to 30 000, tie densities from none to heavy, strided
+    score rows (a column slice of a wider matrix), with and without explicit global indices -- integer-exact vs the oracle."""
+    from oracle import sprc_oracle as O
+    rng = np.random.default_rng(4242)
+    for case in range(40):
+        nq, N, k = int(rng.integers(1, 70)), int(rng.choice([1, 2, 31, 64, 65, 500, 2297, 6346, 30000])), int(rng.integers(1, 65))
+        levels = int(rng.choice([0, 4, 64, 4096]))
+        sim = rng.uniform(-1.0, 1.0, (nq, N)).astype(np.float32)
+        if levels:
+            sim = (np.round(sim * levels) / levels).astype(np.float32)
+        pad = int(rng.integers(0, 9))
+        wide = torch.zeros((nq, N + pad), dtype=torch.float32, device=DEV)
+        wide[:, :N] = torch.from_numpy(sim).to(DEV)
+        d = wide[:, :N]                                      # row stride N + pad
+        kk = min(k, N)
+        want_v, want_i = O.topk_stable(sim, kk)
+        v, i = E.topk(d, k)
+        np.testing.assert_array_equal(i.cpu().numpy()[:, :kk], want_i.astype(np.int32), err_msg=f"case {case} nq={nq} N={N} k={k}")
+        np.testing.assert_array_equal(v.cpu().numpy()[:, :kk], want_v)
+        listed = rng.integers(-1, N, (nq, 5)).astype(np.int32)
+        np.testing.assert_array_equal(E.rank_of(d, torch.from_numpy(listed)).cpu().numpy(), O.rank_of(sim, listed))
+        base = int(rng.integers(0, 1 << 20))
+        _, ib = E.topk(d, k, idx_base=base)
+        np.testing.assert_array_equal(ib.cpu().numpy()[:, :kk], want_i.astype(np.int32) + base)
 
 
 def test_profiler_start_pause_resume_and_busy_time():
