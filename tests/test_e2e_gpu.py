@@ -114,3 +114,29 @@ def test_two_stream_vit_matches_single_stream(tmp_path):
     assert np.isfinite(out["2"]["raw"]).all()
     np.testing.assert_array_equal(out["1"]["raw"], out["2"]["raw"])
     np.testing.assert_array_equal(out["1"]["feats"], out["2"]["feats"])
+
+
+@pytest.mark.parametrize("model_type", ["pretrain", "pretrain_vitL"])
+def test_ragged_batches_against_the_oracle(model_type):
+    """Composite entry points at batch sizes nobody padded for (1, 3, 5 images; 1, 2, 7 queries; captions of every length
+    from 2 to 32 tokens) on a depth-1 backbone + the full Q-Former: fp32 engine vs the CPU oracle, and one engine sized
+    for the largest batch reused for all of them (workspace carving, row maps of the text rows, masks)."""
+    cfg = get_config(model_type, vit_depth=1)
+    sd = synth.make_state_dict(cfg, seed=21)
+    eng = E.Engine(cfg, sd, DEV, dtype="fp32", max_batch=8)
+    for n_img, nq in ((1, 1), (3, 2), (5, 7)):
+        images = synth.make_images(n_img, seed=30 + n_img)
+        ids, mask, ref = synth.make_queries(nq, n_img, seed=40 + nq)
+        for j in range(nq):                                  # caption lengths 2 .. 32 incl. the extremes
+            L = [2, 32, 3, 17, 31, 9, 5][j % 7]
+            ids[j, L - 1], ids[j, L:], mask[j, :L], mask[j, L:] = 102, 0, 1, 0
+        with torch.no_grad():
+            feats_o, raw_o = O.extract_target_features(sd, cfg, images)
+            sim_o = O.inference(sd, cfg, raw_o[ref], feats_o, ids, mask).numpy()
+        raw = eng.vit_forward(images.to(DEV))
+        feats, _ = eng.qformer_image(raw)
+        fusion, _ = eng.qformer_fuse(raw[ref.to(DEV)], ids, mask)
+        sim = E.sim_max(fusion, feats).cpu().numpy()
+        np.testing.assert_allclose(raw.cpu().numpy(), raw_o.numpy(), atol=2e-4, rtol=0)
+        np.testing.assert_allclose(feats.cpu().numpy(), feats_o.numpy(), atol=2e-5, rtol=0)
+        np.testing.assert_allclose(sim.reshape(nq, n_img), sim_o.reshape(nq, n_img), atol=2e-5, rtol=0)
