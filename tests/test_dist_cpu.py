@@ -65,3 +65,12 @@ def test_sharded_ranking_equals_single_process_world2():
             out = mgr.dict()
             mp.spawn(_worker, args=(2, _free_port(), n_total, nq_local, k, out), nprocs=2, join=True)
             assert out[0] and out[1], (n_total, nq_local, k, dict(out))
+
+
+def test_sharded_ranking_equals_single_process_world3_uneven():
+    """three ranks, gallery sizes that do not divide (shards of 34/33/33 and 3/2/2 images, the latter smaller than k)."""
+    for n_total, nq_local, k in [(100, 2, 12), (7, 1, 5)]:
+        with mp.Manager() as mgr:
+            out = mgr.dict()
+            mp.spawn(_worker, args=(3, _free_port(), n_total, nq_local, k, out), nprocs=3, join=True)
+            assert out[0] and out[1] and out[2], (n_total, nq_local, k, dict(out))
