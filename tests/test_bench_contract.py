@@ -1,0 +1,43 @@
+"""The bench line the driver parses: the committed `profiles/r01_bench_n1.json` (an unedited `python bench.py` line apart
+from `roofline.traffic`, which bench.py itself reads from profiles/r01_traffic.json) must carry every field of the
+measurement contract, and the roofline numbers must be self-consistent."""
+import json
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_committed_bench_line_follows_the_contract():
+    d = json.loads((ROOT / "profiles" / "r01_bench_n1.json").read_text())
+    base = json.loads((ROOT / "BASELINE.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None                      # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["dtype"] == "bf16"
+    if isinstance(base.get("metric"), str):
+        assert d["unit"].split("/")[0] in base["metric"] or "images" in d["unit"]
+    # value is whole-job throughput: batch / step time
+    assert abs(d["value"] - d["config"]["batch"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["alg_flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) / r["achieved"] < 2e-2
+    assert r["traffic"] is None or r["traffic"] > 0.5 * r["alg_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
+
+
+def test_committed_rocprof_summary_agrees_with_the_bench_line():
+    import csv
+    d = json.loads((ROOT / "profiles" / "r01_bench_n1.json").read_text())
+    rows = list(csv.DictReader((ROOT / "profiles" / "r01_bench_kernel_stats.csv").open()))
+    gemm_ms = sum(float(r["TotalDurationNs"]) for r in rows if "gemm" in r["Name"] or "splitk" in r["Name"]) / 4e6   # 4 steps profiled
+    ev = d["kernels"]["gemm_bf16"]["ms_per_step"]
+    assert abs(gemm_ms - ev) / ev < 0.03, (gemm_ms, ev)
