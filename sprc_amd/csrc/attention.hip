@@ -314,6 +314,14 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
         SPRC_REQUIRE(((uintptr_t)a->q % 16) == 0 && ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0 &&
                          ((uintptr_t)a->out % 8) == 0, "sprc_attention(bf16): misaligned pointer");
         const bool small = a->Tq <= 128;
+        // 257 tokens = 9 query tiles: nine waves (one tile each, the K / V staging shared by nine) beat eight waves of which
+        // one carries two tiles: 209 -> 195 us per ViT-g layer (SPRC_ATTN_NINE=0 for the A/B)
+        static const int nine = [] { const char* e = getenv("SPRC_ATTN_NINE"); return e ? atoi(e) : 1; }();
+        const int nqt = (a->Tq + 31) / 32;
+        if (nine && nqt == 9) {
+            if (a->head_dim <= 64) return launch_bf16<64, 9>(p, st);
+            return launch_bf16<96, 9>(p, st);
+        }
         if (a->head_dim <= 64) return small ? launch_bf16<64, 4>(p, st) : launch_bf16<64, 8>(p, st);
         return small ? launch_bf16<96, 4>(p, st) : launch_bf16<96, 8>(p, st);
     }
