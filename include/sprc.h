@@ -86,6 +86,12 @@ typedef struct {
 } sprc_gemm_args;
 int sprc_gemm(const sprc_gemm_args* a, sprc_stream s);
 
+/* Two products of identical shape in ONE launch: same A, C, resid, leading dimensions, dtypes, activation and row-map
+ * geometry; `b` may differ from `a` in W, bias and the two row-map group offsets only.  This is the query / text FFN pair
+ * of a Q-Former layer (Qformer.py:455-475: rows [:32] of every sample through intermediate_query / output_query, rows
+ * [32:] through intermediate / output): half-empty grids of the two small products become one full one. */
+int sprc_gemm_pair(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stream s);
+
 /* y = LayerNorm(x) over the last dim (fp32 statistics, two-pass) -- nn.LayerNorm at
  * eva_vit.py:175-176 (eps 1e-6), clip_vit.py:100-106, blip2.py:193-199 (ln_vision, eps 1e-5),
  * Qformer.py:112,294,380 (eps 1e-12).  Writes an fp32 copy (residual stream) and/or a

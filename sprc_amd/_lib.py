@@ -94,6 +94,7 @@ SIGNATURES = {
     "sprc_prof_collect": (i32, [C.POINTER(ProfEntry)]),
     "sprc_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
     "sprc_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "sprc_gemm_pair": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
     "sprc_layernorm": (i32, [C.POINTER(LayerNormArgs), vp]),
     "sprc_attention": (i32, [C.POINTER(AttentionArgs), vp]),
     "sprc_im2row": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),

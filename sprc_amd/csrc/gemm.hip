@@ -43,6 +43,9 @@ struct GemmParams {
     int tiles_m, tiles_n;
     float* scratch; int64_t scratch_elems;   // optional caller scratch (split-K partials)
     int order;                          // tile order (tile_origin): 0 = 8-m grouped, n > 0 = groups of n n-tiles sweeping m
+    int dual;                           // 1: the grid holds TWO products of identical shape; workgroups >= nwg0 take the second set
+    int nwg0;
+    const char* W2; const float* bias2; int a_off2, c_off2;      // what differs in the second product: weight, bias, row-map offsets
     int ksplit;                         // > 1: split-K launch of the 128x128 kernel (grid = tiles x ksplit), raw fp32 partials
     int64_t split_stride;               // elements between the partial planes of consecutive K splits
     int debug;                          // SPRC_GEMM_DEBUG, timing experiments on the 256x256 kernel (results are WRONG with 1 / 2):
@@ -294,6 +297,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
     int vb = blockIdx.x, ks = 0;
+    if (p.dual && vb >= p.nwg0) {                               // second product of a paired launch
+        vb -= p.nwg0;
+        p.W = p.W2; p.bias = p.bias2; p.a_off = p.a_off2; p.c_off = p.c_off2;
+    }
     int64_t kbase = 0;                                          // byte offset of this workgroup's first K-tile
     if (p.ksplit > 1) {                                         // split-K: workgroup (tile vb, split ks) reduces K-tiles [t0, t0 + nt)
         ks = vb / nwg;
@@ -471,8 +478,13 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     uint64_t tile_ts[4] = {0, 0, 0, 0};                      // STAMP build: entry | prologue done | K loop done | epilogue done
     if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
 
+    int vb = blockIdx.x;
+    if (p.dual && vb >= p.nwg0) {                           // second product of a paired launch
+        vb -= p.nwg0;
+        p.W = p.W2; p.bias = p.bias2; p.a_off = p.a_off2; p.c_off = p.c_off2;
+    }
     int m0, n0;
-    tile_origin(blockIdx.x, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
+    tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
     // piece q of this group: q = 0, 1 issued in NC(t,0), q = 2, 3 in NC(t,1):  G0: B0 B1 | A2 A3    G1: B2 B3 | A0 A1
     // (K-tile t+1, except G1's A0 A1 which already belong to K-tile t+2)
     const int ltid = tid & 255, wg = wave & 3;
@@ -691,7 +703,8 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     static const int order = env_int("SPRC_GEMM_ORDER", 0);     // 8-m grouped order is better for the K-heavy 128x128 GEMMs
     p.order = order;
     const int nwg = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(nwg * (p.ksplit > 1 ? p.ksplit : 1)), dim3(64 * WM * WN), LDS, st, p);
+    p.nwg0 = nwg;
+    hipLaunchKernelGGL(kern, dim3(nwg * (p.ksplit > 1 ? p.ksplit : 1) * (p.dual ? 2 : 1)), dim3(64 * WM * WN), LDS, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm");
     return SPRC_OK;
 }
@@ -722,7 +735,8 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     p.tiles_n = (p.N + 255) / 256;
     static const int order = env_int("SPRC_GEMM_ORDER", 4);     // W-resident groups of 4 n-tiles: +8 % on N = 9216, neutral else
     p.order = order;
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS, st, p);
+    p.nwg0 = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(p.nwg0 * (p.dual ? 2 : 1)), dim3(512), LDS, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm(anti)");
     return SPRC_OK;
 }
@@ -754,14 +768,15 @@ static int launch(const GemmParams& p, hipStream_t st) {
             // on the CU can hide) as in its K loop: +35 % per round (14912 x 768 x 768: 46 us on 256x256, 40 on 128x128;
             // 32896 x 1024 x 1024: 131 us peeled, 118 on 128x128)
             const double f256 = (p.K <= 1024 && sizeof(OutT) == 4 && p.resid != nullptr) ? 1.35 : 1.0;
-            auto cost256 = [&](int m) { return f256 * (double)((((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
+            const int64_t mult = p.dual ? 2 : 1;                 // a paired launch carries two products
+            auto cost256 = [&](int m) { return f256 * (double)((mult * ((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
             auto cost128 = [&](int m) {
-                const int64_t t = (int64_t)((m + 127) / 128) * tn128, full = t / (2 * ncu), last = t % (2 * ncu);
+                const int64_t t = mult * ((m + 127) / 128) * tn128, full = t / (2 * ncu), last = t % (2 * ncu);
                 return 0.7 * (double)full + (last == 0 ? 0.0 : last <= ncu ? 0.42 : 0.7);
             };
             const double cA = cost128(p.M), cB = cost256(p.M);
             static const int peel = env_int("SPRC_GEMM_PEEL", 1);
-            const bool can_peel = peel && !MAX32 && p.M > 256 && p.a_shift < 0 && p.c_shift < 0;
+            const bool can_peel = peel && !MAX32 && !p.dual && p.M > 256 && p.a_shift < 0 && p.c_shift < 0;
             double cC = 1e30;
             int Mm = 0;
             if (can_peel) {
@@ -831,7 +846,7 @@ static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st
 
 }  // namespace sprc
 
-extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) {
+static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stream s) {
     using namespace sprc;
     SPRC_REQUIRE(a != nullptr, "sprc_gemm: null args");
     SPRC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "sprc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -865,15 +880,38 @@ extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) {
     }
     p.tiles_m = p.tiles_n = 0;
     p.ksplit = 1; p.split_stride = 0;
+    p.dual = 0; p.nwg0 = 0; p.W2 = nullptr; p.bias2 = nullptr; p.a_off2 = p.c_off2 = 0;
+    if (b != nullptr) {                 // second product of a paired launch: same shapes, operands A / C / resid and row-map geometry
+        SPRC_REQUIRE(!a->max32 && !b->max32, "sprc_gemm_pair: no max32 epilogue");
+        SPRC_REQUIRE(b->M == a->M && b->N == a->N && b->K == a->K && b->dtype == a->dtype && b->out_dtype == a->out_dtype &&
+                         b->act == a->act && b->A == a->A && b->lda == a->lda && b->ldw == a->ldw && b->C == a->C &&
+                         b->ldc == a->ldc && b->resid == a->resid && b->ldr == a->ldr &&
+                         b->amap.rows_per_group == a->amap.rows_per_group && b->amap.group_stride == a->amap.group_stride &&
+                         b->cmap.rows_per_group == a->cmap.rows_per_group && b->cmap.group_stride == a->cmap.group_stride,
+                     "sprc_gemm_pair: the two products may differ in W, bias and the row-map offsets only");
+        SPRC_REQUIRE(b->W != nullptr && ((uintptr_t)b->W % 16) == 0, "sprc_gemm_pair: bad second W");
+        SPRC_REQUIRE((a->bias == nullptr) == (b->bias == nullptr), "sprc_gemm_pair: bias on both products or on neither");
+        p.dual = 1;
+        p.W2 = (const char*)b->W; p.bias2 = b->bias;
+        p.a_off2 = b->amap.group_offset; p.c_off2 = b->cmap.group_offset;
+    }
     p.scratch = reinterpret_cast<float*>(a->scratch); p.scratch_elems = (int64_t)(a->scratch_bytes / 4);
     static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
     p.debug = dbg;
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     hipStream_t st = (hipStream_t)s;
     const double osz = a->max32 ? 4.0 / 32.0 : (double)dtype_size(a->out_dtype);
-    ProfScope prof(a->dtype == SPRC_BF16 ? SPRC_K_GEMM_BF16 : SPRC_K_GEMM_F32, st, 2.0 * a->M * (double)a->N * a->K,
-                   ((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0)));
+    const double np = b != nullptr ? 2.0 : 1.0;
+    ProfScope prof(a->dtype == SPRC_BF16 ? SPRC_K_GEMM_BF16 : SPRC_K_GEMM_F32, st, np * 2.0 * a->M * (double)a->N * a->K,
+                   np * (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))));
     return a->dtype == SPRC_BF16 ? dispatch<bf16_t>(a, p, st) : dispatch<float>(a, p, st);
+}
+
+extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) { return gemm_impl(a, nullptr, s); }
+
+extern "C" int sprc_gemm_pair(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stream s) {
+    SPRC_REQUIRE(a != nullptr && b != nullptr, "sprc_gemm_pair: null args");
+    return gemm_impl(a, b, s);
 }
 
 extern "C" int sprc_sim_max(const void* fusion, const void* feats, float* sim, int64_t ld_sim, int32_t nq, int32_t N,

@@ -37,6 +37,22 @@ static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const v
     return sprc_gemm(&g, st);
 }
 
+// two products of identical shape in one launch (sprc_gemm_pair): w0 on the rows amap0 -> cmap0, w1 on amap1 -> cmap1
+static int gemm2(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w0,
+                 const sprc_linear& w1, void* C, int64_t ldc, int act, const float* resid, int64_t ldr, sprc_rowmap amap0,
+                 sprc_rowmap amap1, sprc_rowmap cmap0, sprc_rowmap cmap1) {
+    sprc_gemm_args g[2];
+    memset(g, 0, sizeof(g));
+    for (int i = 0; i < 2; ++i) {
+        g[i].M = M; g[i].N = N; g[i].K = K; g[i].dtype = dt; g[i].out_dtype = out_dt; g[i].act = act;
+        g[i].A = A; g[i].lda = lda; g[i].amap = i ? amap1 : amap0;
+        g[i].W = (i ? w1 : w0).w; g[i].ldw = K; g[i].bias = (i ? w1 : w0).b;
+        g[i].resid = resid; g[i].ldr = ldr;
+        g[i].C = C; g[i].ldc = ldc; g[i].cmap = i ? cmap1 : cmap0;
+    }
+    return sprc_gemm_pair(&g[0], &g[1], st);
+}
+
 static int lnorm(hipStream_t st, int dt, int M, int D, const float* x, const float* gam, const float* bet, float eps,
                  float* y32, void* y16, sprc_rowmap map = ID_MAP) {
     sprc_layernorm_args a;
@@ -135,14 +151,27 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
                 RUN(gemm(st, dt, SPRC_F32, Rq, Hd, Hd, q.ctx, Hd, L.cross_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, rq));
                 RUN(lnorm(st, dt, Rq, Hd, q.t32, L.cross_ln_w, L.cross_ln_b, m->ln_eps, q.a32, q.a16, rq));
             }
-            RUN(gemm(st, dt, dt, Rq, F, Hd, q.a16, Hd, L.ffn_q_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, rq));
-            RUN(gemm(st, dt, SPRC_F32, Rq, Hd, F, q.ffn, F, L.ffn_q_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, rq));
-            RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, rq));
-            if (split) {
-                const int Rt = B * (S - Lq);
-                RUN(gemm(st, dt, dt, Rt, F, Hd, q.a16, Hd, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, tmap));
-                RUN(gemm(st, dt, SPRC_F32, Rt, Hd, F, q.ffn, F, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, tmap));
-                RUN(lnorm(st, dt, Rt, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
+            if (split && S - Lq == Lq) {
+                // query rows and text rows of every sample go through different FFN weights (Qformer.py:455-475): the two
+                // products have the same shape, so each pair is ONE launch (sprc_gemm_pair) -- 360 + 360 tiles instead of two
+                // 1.4-round grids for the up projection, 90 + 90 instead of two third-empty grids for the down projection.
+                // The hidden activations keep the rows' natural positions in q.ffn [R, F].
+                RUN(gemm2(st, dt, dt, Rq, F, Hd, q.a16, Hd, L.ffn_q_in, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, qmap, tmap,
+                          qmap, tmap));
+                RUN(gemm2(st, dt, SPRC_F32, Rq, Hd, F, q.ffn, F, L.ffn_q_out, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, qmap,
+                          tmap, qmap, tmap));
+                RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, qmap));
+                RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
+            } else {
+                RUN(gemm(st, dt, dt, Rq, F, Hd, q.a16, Hd, L.ffn_q_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, rq));
+                RUN(gemm(st, dt, SPRC_F32, Rq, Hd, F, q.ffn, F, L.ffn_q_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, rq));
+                RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, rq));
+                if (split) {
+                    const int Rt = B * (S - Lq);
+                    RUN(gemm(st, dt, dt, Rt, F, Hd, q.a16, Hd, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, tmap));
+                    RUN(gemm(st, dt, SPRC_F32, Rt, Hd, F, q.ffn, F, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, tmap));
+                    RUN(lnorm(st, dt, Rt, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
+                }
             }
         } else {
             RUN(gemm(st, dt, dt, R, F, Hd, q.a16, Hd, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU));

@@ -55,6 +55,28 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None
     return out
 
 
+def gemm_pair(A: torch.Tensor, W0: torch.Tensor, W1: torch.Tensor, bias0, bias1, amap0, amap1, cmap0, cmap1, M: int,
+              out: torch.Tensor, resid=None, out_dtype=None, act=L.ACT_NONE) -> torch.Tensor:
+    """Two products of identical shape in one launch (sprc_gemm_pair): rows amap0 of A through W0 into rows cmap0 of `out`,
+    rows amap1 through W1 into rows cmap1."""
+    lib = L.load()
+    dt = L.SPRC_BF16 if A.dtype == torch.bfloat16 else L.SPRC_F32
+    N, K = W0.shape
+    odt = dt if out_dtype is None else out_dtype
+    gs = []
+    for W, bias, amap, cmap in ((W0, bias0, amap0, cmap0), (W1, bias1, amap1, cmap1)):
+        g = L.GemmArgs()
+        g.M, g.N, g.K, g.dtype, g.out_dtype, g.act, g.max32 = M, N, K, dt, odt, act, 0
+        g.A, g.lda, g.amap = A.data_ptr(), A.stride(0), amap
+        g.W, g.ldw = W.data_ptr(), W.stride(0)
+        g.bias = _ptr(bias)
+        g.resid, g.ldr = _ptr(resid), (resid.stride(0) if resid is not None else 0)
+        g.C, g.ldc, g.cmap = out.data_ptr(), out.stride(0), cmap
+        gs.append(g)
+    L.check(lib.sprc_gemm_pair(C.byref(gs[0]), C.byref(gs[1]), _stream()), "sprc_gemm_pair")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype: int, want32=True, want16=True,
               xmap=None, ymap=None, M=None, y32=None, y16=None):
     lib = L.load()

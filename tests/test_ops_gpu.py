@@ -167,6 +167,40 @@ def test_gemm_rowmaps():
     torch.testing.assert_close(out1, A[32::64].float() @ W.float().t(), atol=2e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("Bn,N,K,act,out32", [(233, 3072, 768, L.ACT_GELU, False), (233, 768, 3072, L.ACT_NONE, True),
+                                              (5, 256, 128, L.ACT_NONE, True), (40, 768, 768, L.ACT_QUICKGELU, False)])
+def test_gemm_pair_equals_two_launches(Bn, N, K, act, out32):
+    """sprc_gemm_pair (the query / text FFN pair of a Q-Former layer): rows [:32] of every 64-row sample through W0, rows
+    [32:] through W1, in one launch -- identical to the two separate row-mapped launches, and close to float64."""
+    A = _bf(_rand((Bn * 64, K), 51)).to(DEV)
+    W0, W1 = _bf(_rand((N, K), 52, 0.05)).to(DEV), _bf(_rand((N, K), 53, 0.05)).to(DEV)
+    b0, b1 = _rand((N,), 54).to(DEV), _rand((N,), 55).to(DEV)
+    r = _rand((Bn * 64, N), 56).to(DEV) if out32 else None
+    odt = L.SPRC_F32 if out32 else L.SPRC_BF16
+    qmap, tmap = E.rowmap(32, 64, 0), E.rowmap(32, 64, 32)
+    mk = lambda: torch.full((Bn * 64, N), 7.0, dtype=torch.float32 if out32 else torch.bfloat16, device=DEV)
+    one = E.gemm_pair(A, W0, W1, b0, b1, qmap, tmap, qmap, tmap, Bn * 32, mk(), resid=r, out_dtype=odt, act=act)
+    two = mk()
+    E.gemm(A, W0, bias=b0, resid=r, out_dtype=odt, act=act, out=two, M=Bn * 32, amap=qmap, cmap=qmap)
+    E.gemm(A, W1, bias=b1, resid=r, out_dtype=odt, act=act, out=two, M=Bn * 32, amap=tmap, cmap=tmap)
+    torch.testing.assert_close(one.float(), two.float(), atol=1e-2 if not out32 else 1e-4, rtol=1e-2 if not out32 else 1e-5)
+    rows = torch.arange(Bn * 64)
+    is_q = (rows % 64) < 32
+    z = torch.where(is_q[:, None], A.cpu().double() @ W0.cpu().double().t() + b0.cpu().double(),
+                    A.cpu().double() @ W1.cpu().double().t() + b1.cpu().double())
+    if act == L.ACT_GELU:
+        z = torch.nn.functional.gelu(z)
+    elif act == L.ACT_QUICKGELU:
+        z = z * torch.sigmoid(1.702 * z)
+    if r is not None:
+        z = z + r.cpu().double()
+    tol = 3e-3 * math.sqrt(K / 64) if out32 else 4e-2
+    torch.testing.assert_close(one.cpu().double(), z, atol=tol, rtol=1.6e-2 if not out32 else 1e-4)
+    with pytest.raises(L.SprcError, match="differ"):
+        E.gemm_pair(A, W0, W1[:, :K // 2].contiguous() if False else W1, b0, b1, qmap, E.rowmap(16, 64, 32), qmap, tmap, Bn * 32, mk(),
+                    resid=r, out_dtype=odt, act=act)
+
+
 def test_gemm_rejects_bad_arguments():
     A, W = _bf(_rand((8, 48), 1)).to(DEV), _bf(_rand((8, 48), 2)).to(DEV)
     with pytest.raises(L.SprcError, match="multiple"):
