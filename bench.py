@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backbone", default="pretrain", choices=["pretrain", "pretrain_vitL"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prof-every", type=int, default=5, help="record per-launch HIP events on every Nth timed step (0 = never)")
+    ap.add_argument("--prof-every", type=int, default=10, help="record per-launch HIP events on every Nth timed step, starting with the first (0 = never)")
     ap.add_argument("--vit-streams", type=int, default=1, help="2 = pipeline the two halves of a batch on two streams inside sprc_vit_forward (+4 %% images/s; per-kernel timings then overlap)")
     ap.add_argument("--cpu-images", type=int, default=32, help="size of the bounded CPU-baseline sample (~15 s of CPU work on 16 cores)")
     return ap.parse_args()
