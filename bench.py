@@ -33,6 +33,21 @@ GALLERY, QUERIES, BATCH, TOPK = 2297, 4181, 128, 51
 Q_PER_STEP = (BATCH * QUERIES + GALLERY - 1) // GALLERY          # 233 -> keep CIRR-val's query:image ratio
 MFMA_BF16_PEAK_TFLOPS = 2500.0                                    # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+# the GEMM class = every launch of these kernels (sprc_amd/csrc/gemm.hip); the 256x256 anti-phase kernel carries > 95 % of
+# the class time at the bench shapes, the 128x128 kernel the remainder rows and the small Q-Former products
+GEMM_KERNELS = {"bf16": "sprc::gemm_anti_kernel<...> (256x256 anti-phase, dominant) + sprc::gemm_kernel<bf16,...> (128x128)",
+                "fp32": "sprc::gemm_kernel<float,...> (exact fp32 MFMA)"}
+
+
+def kernel_source_sha() -> str:
+    """sha256 over the HIP sources: ties a committed counter profile to the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sprc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def parse():
@@ -88,27 +103,56 @@ def cpu_baseline(cfg, n_img: int):
                       f"{t2 - t1:.1f}s, query cost scaled to {QUERIES}/{GALLERY} queries per image"}
 
 
+def respawn(n: int) -> int:
+    """`bench.py --gpus N` outside a launcher: start N ranks of this script under torch.distributed.run (one per GPU;
+    rank r on GPU r, or r % visible GPUs when fewer are visible -- see `backend` in main)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(respawn(a.gpus))
     if a.vit_streams != 1:
         os.environ["SPRC_VIT_STREAMS"] = str(a.vit_streams)      # read once by the library at its first ViT forward
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path (no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % ndev)
+    torch.cuda.set_device(dev)
+    # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm).  With fewer visible GPUs than ranks (a 1-GPU box running
+    # `--gpus 2` as a plumbing check) the ranks share devices and the two tiny all_gathers are staged through gloo:
+    # RCCL refuses two ranks on one device.  The line then says so in config.backend -- it is not a scaling number.
+    backend = "nccl" if world <= ndev else "gloo"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        assert dist.get_world_size() == a.gpus
 
     from sprc_amd import _lib as L
     from sprc_amd import engine as E
     from sprc_amd import synth
     from sprc_amd.config import get_config
-    from sprc_amd.dist import ShardedRanker
+    from sprc_amd.dist import ShardedRanker, owner_of, shard_bounds
 
     lib = L.load()
     cfg = get_config(a.backbone)
@@ -123,7 +167,12 @@ def main():
     ids, mask = ids.to(dev), mask.to(dev)
     ref_slot = (7919 * torch.arange(Q_PER_STEP, device=dev)) % BATCH             # references come from the batch's raw embeds
     gallery = torch.nn.functional.normalize(torch.randn((GALLERY, 32, cfg.embed_dim), generator=g, device=dev), dim=-1)
-    ranker = ShardedRanker(gallery, index_base=rank * GALLERY)
+    # weak scaling: the global gallery has world x 2297 images in contiguous, balanced shards; a query is fused on the rank
+    # that owns its reference image (sprc_amd/dist.py: owner_of) -- here every rank draws references from its own batch
+    lo_g, hi_g = shard_bounds(world * GALLERY, world, rank)
+    assert (lo_g, hi_g) == (rank * GALLERY, (rank + 1) * GALLERY)
+    assert bool((owner_of(lo_g + ref_slot.cpu(), world * GALLERY, world) == rank).all())
+    ranker = ShardedRanker(gallery, index_base=lo_g)
     raw = torch.empty((BATCH, cfg.vit.tokens, cfg.vit.width), dtype=torch.float32, device=dev)
 
     def step(i: int):
@@ -181,13 +230,16 @@ def main():
                    for j, n in enumerate(L.K_CLASSES) if prof[j].launches}
         # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside this process, so the figure comes from the
         # committed rocprofv3 passes over this same command (tools/profile_bench.sh -> profiles/r01_traffic.json)
+        # -- and only when that profile was taken on THIS build (it records the hash of the kernel sources): otherwise null
         traffic, traffic_src = None, None
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if a.dtype == "bf16" and a.backbone == "pretrain" and os.path.exists(tj) and pe.launches:
             with open(tj) as f:
-                per_step = json.load(f)["gemm_bytes_per_step"]["total"]
-            traffic = round(per_step / (pe.launches / n_prof), 1)
-            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only passes)"
+                tr = json.load(f)
+            if tr.get("kernel_source_sha") == kernel_source_sha():
+                traffic = round(tr["gemm_bytes_per_step"]["total"] / (pe.launches / n_prof), 1)
+                traffic_src = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only "
+                               "passes over this command on this build: kernel_source_sha %s)" % tr["kernel_source_sha"][:12])
         out = {
             "metric": "gallery images encoded+ranked/sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -196,8 +248,9 @@ def main():
                                    f"{'ViT-g' if a.backbone == 'pretrain' else 'ViT-L'} {a.dtype}, batch {BATCH}; step = encode {BATCH} images + "
                                    f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
-                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams},
-            "roofline": {"bound": "mfma", "kernel": "sprc::gemm_kernel<%s>" % a.dtype, "achieved": round(ach, 1), "peak": peak,
+                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams,
+                       "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if world > 1 else None},
+            "roofline": {"bound": "mfma", "kernel": GEMM_KERNELS[a.dtype], "achieved": round(ach, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(pe.bytes / max(pe.launches, 1), 1),

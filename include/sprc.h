@@ -28,10 +28,12 @@
 extern "C" {
 #endif
 
-#define SPRC_ABI_VERSION 1
+#define SPRC_ABI_VERSION 2
 
 enum { SPRC_OK = 0, SPRC_EINVAL = -1, SPRC_ELAUNCH = -2, SPRC_EWORKSPACE = -3, SPRC_EUNSUPPORTED = -4 };
-enum { SPRC_F32 = 0, SPRC_BF16 = 1 };
+enum { SPRC_F32 = 0, SPRC_BF16 = 1,
+       SPRC_F16 = 2 /* OUTPUT-only dtype of sprc_gemm: a residual-branch output ("delta") that sprc_layernorm adds to the
+                       fp32 residual stream (11-bit mantissa: 8x finer than the bf16 GEMM operands) */ };
 enum { SPRC_ACT_NONE = 0, SPRC_ACT_GELU = 1, SPRC_ACT_QUICKGELU = 2 };
 
 typedef void* sprc_stream;                    /* hipStream_t */
@@ -69,6 +71,7 @@ int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream
  * eva_vit.py:123,146,55-60; clip_vit.py:132-139; Qformer.py:135-137,201-211,291-293,365,377;
  * align_prompt.py:348,385.  A and W are `dtype`; bias/resid fp32; out is `out_dtype`.
  * K % 64 == 0 (bf16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (bf16) / 4 (f32) elements.
+ * out_dtype SPRC_F16: bf16 operands only, no activation / residual / max32 (see sprc_layernorm_args.add16).
  *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
  * max32 != 0: "similarity" epilogue -- rows of A are query vectors, rows of W are gallery tokens (32 per
  * image); out[m*ldc + n/32] = max over the 32 W-rows of image n/32 (align_prompt.py:353-358). */
@@ -102,6 +105,14 @@ typedef struct {
     const float* gamma; const float* beta; float eps;
     float* y32;      int64_t ld32; sprc_rowmap ymap;
     void*  y16;      int64_t ld16;              /* rows mapped with ymap as well */
+    /* Optional fused residual add (bf16 engine): the normalised row is x + add16, with add16 the fp16 output of the branch
+     * GEMM (attention proj / MLP fc2 / BERT output.dense: eva_vit.py:178-179, clip_vit.py:137-138, Qformer.py:294,380).
+     * The fp32 + residual GEMM epilogue it replaces was an un-overlapped HBM burst (8 B per element with the matrix pipe
+     * idle); here the add rides on a pass that reads x anyway.  add16 rows are mapped like x (xmap); it may alias y16
+     * (a wave holds its whole row in registers before it stores).  sum32 (optional, rows mapped like x, may alias x)
+     * receives x + add16: the pre-LN residual-stream update. */
+    const void* add16; int64_t ld_add;
+    float* sum32;      int64_t ld_sum;
 } sprc_layernorm_args;
 int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s);
 

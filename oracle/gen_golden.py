@@ -12,6 +12,8 @@ Files written:
   tests/golden/tiny_clip.npz   ViT-L width, depth 2                    : every stage boundary
   tests/golden/full_eva.npz    full depth (39 blocks), 2 images, 3 queries   (--full, ~3 min)
   tests/golden/full_clip.npz   full depth ViT-L (23 blocks), 2 images, 3 queries   (--full)
+  tests/golden/planted_eva.npz planted-structure weights (scores spread > 1.0), depth-4 ViT-g, 160 gallery x 72 queries:
+                               scores, planned targets, the reference's own metrics / submission dicts on them
   tests/golden/metrics.json    reference compute_cirr_val_metrics / compute_fiq_val_metrics /
                                generate_cirr_test_dicts on synthetic sims (with engineered ties)
   tests/golden/captions.json   reference BlipCaptionProcessor + FashionIQ caption composition
@@ -167,6 +169,107 @@ def metrics_goldens(out: Path):
     print("wrote", out)
 
 
+PLANT_RANKS = [0, 0, 1, 2, 3, 4, 5, 8, 9, 10, 15, 30, 48, 49, 50, 51, 75, 120]   # planned rank of the target (reference removed)
+
+
+def planted_targets(sim: np.ndarray, ref: np.ndarray, seed: int = 0, margin: float = 5e-3):
+    """Targets / subset groups for a planted-structure retrieval case: query q's target is the gallery image the
+    REFERENCE ranks at position PLANT_RANKS[q % len] (after removing the reference image, validate_blip.py:258-261),
+    moved to the nearest position whose score differs from both neighbours by more than `margin` (so that a K boundary
+    never sits on a near-tie: Recall@K of a bf16 run is then decided by structure, not by rounding)."""
+    rng = np.random.default_rng(seed)
+    nq, N = sim.shape
+    d = (np.float32(1.0) - sim.astype(np.float32)).astype(np.float32)
+    order = np.argsort(d, axis=1, kind="stable")
+    tgt = np.zeros(nq, dtype=np.int64)
+    groups = np.zeros((nq, 6), dtype=np.int64)
+    for q in range(nq):
+        o = order[q][order[q] != ref[q]]
+        dq = d[q][o]
+        want = PLANT_RANKS[q % len(PLANT_RANKS)]
+        ok = [p for p in range(1, N - 2) if dq[p] - dq[p - 1] > margin and dq[p + 1] - dq[p] > margin]
+        if want == 0 and dq[1] - dq[0] > margin:
+            pos = 0
+        else:
+            pos = min(ok, key=lambda p: (abs(p - want), p))
+        tgt[q] = o[pos]
+        others = [i for i in rng.permutation(N) if i != ref[q] and i != tgt[q]][:4]
+        groups[q] = rng.permutation(np.array([ref[q], tgt[q], *others]))
+    return tgt, groups
+
+
+def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int = 4, seed: int = 0):
+    """Planted-structure ordering fixture: depth-4 ViT-g + the full Q-Former run by the REFERENCE on 160 gallery images
+    and 72 composed queries; scores spread over > 1.0; targets at planned ranks; the reference's own
+    compute_cirr_val_metrics / compute_fiq_val_metrics / generate_cirr_test_dicts evaluated on its own scores."""
+    from torch.utils.data import Dataset
+    cfg = get_config("pretrain", vit_depth=vit_depth)
+    sd = synth.make_state_dict(cfg, seed=seed, planted=True)
+    model = ref_import.build_reference_model(cfg, sd)
+    images = synth.make_images(n_img, seed=seed, planted=True)
+    ids, mask, ref = synth.make_queries(n_q, n_img, seed=seed + 1)
+    feats, raw = [], []
+    with torch.no_grad():
+        for s in range(0, n_img, 32):
+            f, r = model.extract_target_features(images[s:s + 32], mode="mean")
+            feats.append(f); raw.append(r)
+        feats, raw = torch.cat(feats), torch.cat(raw)
+        sims, fus = [], []
+        calls = []
+        h = model.Qformer.bert.register_forward_hook(lambda m, a, k, o: calls.append(o.last_hidden_state.clone()), with_kwargs=True)
+        for s in range(0, n_q, 24):
+            model.tokenizer.set_next(ids[s:s + 24], mask[s:s + 24])
+            calls.clear()
+            sims.append(model.inference(raw[ref[s:s + 24]], feats, ["caption"] * len(ids[s:s + 24])))
+            fus.append(torch.nn.functional.normalize(model.text_proj(calls[1][:, 32, :]), dim=-1))
+        h.remove()
+    sim, fusion = _np(torch.cat(sims)), _np(torch.cat(fus))
+    refn = ref.numpy()
+    tgt, groups = planted_targets(sim, refn, seed)
+    # the reference's own metric code on the reference's own scores
+    vb, cts = ref_import.import_harness()
+    names = [f"img-{i:05d}" for i in range(n_img)]
+
+    class FakeModel:
+        device = torch.device("cpu")
+
+        def inference(self, reference_embeds, target_feats, captions):
+            return torch.from_numpy(sim[[int(c[1:]) for c in captions]])
+
+    class CirrVal(Dataset):
+        def __len__(self):
+            return n_q
+
+        def __getitem__(self, i):
+            return names[refn[i]], names[tgt[i]], f"q{i}", [names[g] for g in groups[i]]
+
+    class CirrTest(CirrVal):
+        def __getitem__(self, i):
+            return 1000 + i, names[refn[i]], f"q{i}", [names[g] for g in groups[i]]
+
+    class FiqVal(CirrVal):
+        dress_types = ["dress"]
+
+        def __getitem__(self, i):
+            return names[refn[i]], names[tgt[i]], [f"q{i}", "x"]
+
+    txt = {"eval": lambda c: c}
+    fk = (torch.zeros(n_img, 1), torch.zeros(n_img, 1))
+    cirr = vb.compute_cirr_val_metrics(CirrVal(), FakeModel(), fk, names, txt)
+    fiq = vb.compute_fiq_val_metrics(FiqVal(), FakeModel(), fk, names, {"eval": lambda c: "q" + c.split(" ")[0][1:]})
+    top, sub = cts.generate_cirr_test_dicts(CirrTest(), FakeModel(), fk, names, txt, False)
+    s_sorted = np.sort(sim, axis=1)
+    gaps = np.diff(s_sorted, axis=1)
+    np.savez_compressed(
+        out, model_type="pretrain", vit_depth=vit_depth, seed=seed, n_img=n_img, n_q=n_q,
+        image_probe=_np(images[:4, :, 0, :4]), input_ids=ids.numpy(), attention_mask=mask.numpy(), ref_index=refn,
+        tgt_index=tgt, groups=groups, sim=sim, fusion=fusion, feats_head=_np(feats[:4]), raw_head=_np(raw[:2][:, ROWS]),
+        cirr=np.array(cirr, dtype=np.float64), fiq=np.array(fiq, dtype=np.float64),
+        test_dicts=np.array(json.dumps({"top": top, "sub": sub})))
+    print(f"wrote {out}: sim range [{sim.min():.3f},{sim.max():.3f}] mean row spread {np.mean(s_sorted[:, -1] - s_sorted[:, 0]):.3f} "
+          f"median gap {np.median(gaps):.1e} gaps<1e-5: {int((gaps < 1e-5).sum())}/{gaps.size}  cirr {[round(x, 2) for x in cirr]} fiq {fiq}")
+
+
 def caption_goldens(out: Path):
     import importlib
     import types
@@ -222,6 +325,8 @@ def main():
         model_goldens("pretrain", 2, n_img=4, n_q=6, out=GOLD / "tiny_eva.npz")
     if want("tiny_clip"):
         model_goldens("pretrain_vitL", 2, n_img=3, n_q=4, out=GOLD / "tiny_clip.npz")
+    if want("planted"):
+        planted_goldens(GOLD / "planted_eva.npz")
     if a.full and want("full_eva"):
         model_goldens("pretrain", None, n_img=2, n_q=3, out=GOLD / "full_eva.npz")
     if a.full and want("full_clip"):

@@ -10,7 +10,8 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libsprc_hip.so"
 
-SPRC_F32, SPRC_BF16 = 0, 1
+SPRC_F32, SPRC_BF16, SPRC_F16 = 0, 1, 2          # SPRC_F16: GEMM output only (residual-branch deltas)
+ABI_VERSION = 2
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16}
 
@@ -31,7 +32,7 @@ class GemmArgs(C.Structure):
 class LayerNormArgs(C.Structure):
     _fields_ = [("M", i32), ("D", i32), ("out_dtype", i32), ("x", vp), ("ldx", i64), ("xmap", RowMap),
                 ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("ld32", i64), ("ymap", RowMap),
-                ("y16", vp), ("ld16", i64)]
+                ("y16", vp), ("ld16", i64), ("add16", vp), ("ld_add", i64), ("sum32", vp), ("ld_sum", i64)]
 
 
 class AttentionArgs(C.Structure):
@@ -134,6 +135,8 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)           # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    if lib.sprc_version() != ABI_VERSION:
+        raise SprcError(f"{LIB_PATH} speaks ABI {lib.sprc_version()}, this binding {ABI_VERSION}: rebuild (python -m sprc_amd.build)")
     _lib = lib
     return lib
 

@@ -19,22 +19,41 @@ from .model import load_model_and_preprocess
 
 
 def _device():
-    if not torch.cuda.is_available():
-        raise SystemExit("sprc_amd needs an MI355X: the HIP kernels are the only compute path")
-    return torch.device("cuda")
+    """cuda:LOCAL_RANK, and the process group when started under torchrun (`torchrun --nproc-per-node 8 -m
+    sprc_amd.blip_validate ...`: one rank per GPU, RCCL)."""
+    from .dist_eval import init_from_env
+    dev, _, _ = init_from_env()
+    return dev
+
+
+def model_fingerprint(model) -> str:
+    """sha256 over the model's state dict (names, shapes, bytes): the identity of the checkpoint that produced a feature
+    store.  Features of one checkpoint must never be ranked with the queries of another."""
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in sorted(model.state_dict().items()):
+        t = v.detach().to("cpu").contiguous()
+        h.update(k.encode()); h.update(str(tuple(t.shape)).encode()); h.update(str(t.dtype).encode())
+        h.update(t.view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+    return h.hexdigest()
 
 
 def _gallery(dataset, model, cache, tag, backbone, dtype):
-    """Encoded gallery `((feats, raw), names)`: from the feature store `<cache>/<tag>.safetensors` when it exists, else
-    encoded now (and stored when a cache directory was given).  No reference counterpart: utils.py:46-77 re-encodes."""
-    path = os.path.join(cache, f"{tag}-{backbone}-{dtype}.safetensors") if cache else None
-    if path and os.path.exists(path):
+    """Encoded gallery `((feats, raw), names)`: from the feature store `<cache>/<tag>-...-<checkpoint fingerprint>.safetensors`
+    when it exists AND was written by this checkpoint, else encoded now (and stored when a cache directory was given).
+    No reference counterpart: utils.py:46-77 re-encodes on every run."""
+    if not cache:
+        return extract_index_blip_features(dataset, model)
+    fp = model_fingerprint(model)
+    path = os.path.join(cache, f"{tag}-{backbone}-{dtype}-{fp[:16]}.safetensors")
+    if os.path.exists(path):
         (feats, raw), names, meta = load_index(path, device=model.device)
-        print(f"loaded {len(names)} gallery rows from {path} ({meta})")
-        return (feats, raw), names
+        if meta.get("checkpoint_sha256") == fp:
+            print(f"loaded {len(names)} gallery rows from {path} ({meta})")
+            return (feats, raw), names
+        print(f"{path}: written by another checkpoint ({meta.get('checkpoint_sha256', '?')[:16]}), re-encoding")
     (feats, raw), names = extract_index_blip_features(dataset, model)
-    if path:
-        save_index(path, feats, names, raw=raw, backbone=backbone, compute_dtype=dtype)
+    save_index(path, feats, names, raw=raw, backbone=backbone, compute_dtype=dtype, checkpoint_sha256=fp)
     return (feats, raw), names
 
 
@@ -48,19 +67,33 @@ def _load(blip_model_name, backbone, model_path, dtype):
     return model, txt
 
 
+def _sharded() -> bool:
+    """Started under torchrun with more than one rank: the gallery is sharded over the ranks (sprc_amd/dist_eval.py)."""
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1
+
+
+def _rank0() -> bool:
+    return int(os.environ.get("RANK", "0")) == 0
+
+
 def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16", index_cache=None):
     from .data_utils import CIRRDataset, targetpad_transform
     model, txt = _load(blip_model_name, backbone, blip_model_path, dtype)
     preprocess = targetpad_transform(1.25, 224)
     relative_val = CIRRDataset("val", "relative", preprocess)
     classic_val = CIRRDataset("val", "classic", preprocess)
-    feats, names = _gallery(classic_val, model, index_cache, "cirr-val", backbone, dtype)
-    r = compute_cirr_val_metrics(relative_val, model, feats, names, txt)
+    if _sharded():
+        from .dist_eval import compute_cirr_val_metrics_sharded
+        r = compute_cirr_val_metrics_sharded(relative_val, classic_val, model, txt)
+    else:
+        feats, names = _gallery(classic_val, model, index_cache, "cirr-val", backbone, dtype)
+        r = compute_cirr_val_metrics(relative_val, model, feats, names, txt)
     g1, g2, g3, r1, r5, r10, r50 = r
     out = {"group_recall_at1": g1, "group_recall_at2": g2, "group_recall_at3": g3, "recall_at1": r1, "recall_at5": r5,
            "recall_at10": r10, "recall_at50": r50, "mean(R@5+R_s@1)": (g1 + r5) / 2, "arithmetic_mean": mean(r),
            "harmonic_mean": harmonic_mean(r), "geometric_mean": geometric_mean(r)}
-    print(json.dumps(out, indent=4))
+    if _rank0():
+        print(json.dumps(out, indent=4))
     return out
 
 
@@ -72,8 +105,13 @@ def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dt
     preprocess = targetpad_transform(1.25, 224)
     r10s, r50s = [], []
     for d in val_dress_types:
-        feats, names = _gallery(FashionIQDataset("val", [d], "classic", preprocess), model, index_cache, f"fiq-val-{d}", backbone, dtype)
-        r10, r50 = compute_fiq_val_metrics(FashionIQDataset("val", [d], "relative", preprocess), model, feats, names, txt)
+        classic, relative = FashionIQDataset("val", [d], "classic", preprocess), FashionIQDataset("val", [d], "relative", preprocess)
+        if _sharded():
+            from .dist_eval import compute_fiq_val_metrics_sharded
+            r10, r50 = compute_fiq_val_metrics_sharded(relative, classic, model, txt)
+        else:
+            feats, names = _gallery(classic, model, index_cache, f"fiq-val-{d}", backbone, dtype)
+            r10, r50 = compute_fiq_val_metrics(relative, model, feats, names, txt)
         r10s.append(r10)
         r50s.append(r50)
         torch.cuda.empty_cache()
@@ -82,7 +120,8 @@ def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dt
         out[f"{d}_recall_at10"], out[f"{d}_recall_at50"] = a, b
     out.update({"average_recall_at10": mean(r10s), "average_recall_at50": mean(r50s),
                 "average_recall": (mean(r50s) + mean(r10s)) / 2})
-    print(json.dumps(out, indent=4))
+    if _rank0():
+        print(json.dumps(out, indent=4))
     return out
 
 

@@ -15,10 +15,17 @@ from .harness import extract_index_blip_features, generate_cirr_test_dicts
 
 def generate_cirr_test_submissions(file_name: str, blip_model, preprocess, txt_processors, rerank=False):
     from .data_utils import CIRRDataset, base_path
+    import os
     classic = CIRRDataset("test1", "classic", preprocess)
-    feats, names = extract_index_blip_features(classic, blip_model)
     relative = CIRRDataset("test1", "relative", preprocess)
-    top, sub = generate_cirr_test_dicts(relative, blip_model, feats, names, txt_processors, rerank)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not rerank:       # torchrun: gallery sharded over the ranks
+        from .dist_eval import generate_cirr_test_dicts_sharded
+        top, sub = generate_cirr_test_dicts_sharded(relative, classic, blip_model, txt_processors)
+        if int(os.environ.get("RANK", "0")) != 0:
+            return
+    else:
+        feats, names = extract_index_blip_features(classic, blip_model)
+        top, sub = generate_cirr_test_dicts(relative, blip_model, feats, names, txt_processors, rerank)
     submission = {"version": "rc2", "metric": "recall", **top}
     group_submission = {"version": "rc2", "metric": "recall_subset", **sub}
     folder = base_path / "submission" / "CIRR"

@@ -220,6 +220,179 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming bf16 kernel for long query axes (the ViT blocks: Tq = Tk = 257).  The resident-K/V kernel above needs
+// 110 KB of LDS for a ViT-g head, i.e. ONE workgroup per CU: its 60 us of staging per layer never overlapped its 144 us
+// of compute.  Here a workgroup is 3 waves = 96 queries of one (image, head) and walks the keys in 32-key tiles that are
+// double-buffered in LDS (2 x 13.5 KB): global loads of tile t+1 are issued before the MFMAs of tile t and written to
+// the other buffer afterwards (register staging, one barrier per tile), so five workgroups fit on a CU (LDS 27 KB,
+// <= 128 VGPRs) and one workgroup's loads, softmax VALU and stores run under its neighbours' MFMAs.
+// The three workgroups of an (image, head) re-stream the same K/V: the block index is remapped so that they run
+// back to back on ONE XCD (block b runs on XCD b % 8) and the re-reads hit that XCD's L2.
+// Same math as above: S^T = K.Q^T (a lane owns one query column), online softmax in the exp2 domain, O^T = V^T.P^T with P
+// kept in registers; V is transposed on its way into LDS (two keys per 32-bit write).
+template <int DHP>
+__global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int nqb, int xcd_map) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT = 192, KS = DHP / 16, DT = DHP / 32, CPR = DHP / 8;
+    constexpr int KROW = DHP * 2 + 16;        // bytes per K row in LDS (conflict-free ds_read_b128 across 32 rows)
+    constexpr int VROW = 32 * 2 + 8;          // bytes per V^T row of one 32-key tile
+    constexpr int KBYTES = 32 * KROW, BUF = KBYTES + DHP * VROW;
+    constexpr int KPT = (32 * CPR + NT - 1) / NT;              // 16-B K pieces per thread per tile
+    static_assert(16 * CPR <= NT, "one (key pair, chunk) item of V per thread");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, half = lane >> 5;
+    int bh, qb;
+    if (xcd_map) { const int x = blockIdx.x & 7, i = blockIdx.x >> 3; qb = i % nqb; bh = (i / nqb) * 8 + x; }
+    else { bh = blockIdx.x / nqb; qb = blockIdx.x % nqb; }
+    const int b = bh / p.H, h = bh % p.H, dh = p.dh;
+    const int nkt = (p.Tk + 31) >> 5;
+    const char* kbase = p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2;
+    const char* vbase = p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2;
+
+    // ---- this thread's share of a tile: KPT 16-B pieces of K, one (key pair, 8-wide chunk) item of V ----
+    int k_row[KPT], k_c[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) { const int idx = tid + u * NT; k_row[u] = idx / CPR; k_c[u] = idx % CPR; }
+    const int v_kp = tid & 15, v_c = tid >> 4;
+    const bool v_item = v_c < CPR;
+    u32x4 kreg[KPT], va, vb;
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) {
+            const int t = kt * 32 + k_row[u];
+            kreg[u] = u32x4{0u, 0u, 0u, 0u};
+            if (k_row[u] < 32 && t < p.Tk && k_c[u] * 8 < dh)
+                kreg[u] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)t * p.ldk * 2 + k_c[u] * 16);
+        }
+        va = vb = u32x4{0u, 0u, 0u, 0u};
+        const int t0 = kt * 32 + v_kp * 2;
+        if (v_item && v_c * 8 < dh) {
+            if (t0 < p.Tk) va = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t0 * p.ldv * 2 + v_c * 16);
+            if (t0 + 1 < p.Tk) vb = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(t0 + 1) * p.ldv * 2 + v_c * 16);
+        }
+    };
+    auto commit = [&](int buf) {
+        char* sK = smem + buf * BUF;
+        char* sV = sK + KBYTES;
+#pragma unroll
+        for (int u = 0; u < KPT; ++u)
+            if (k_row[u] < 32) *reinterpret_cast<u32x4*>(sK + k_row[u] * KROW + k_c[u] * 16) = kreg[u];
+        if (v_item) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t lo = (va[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                const uint32_t hi = (vb[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e) * VROW + v_kp * 4) = lo | (hi << 16);
+            }
+        }
+    };
+    fetch(0);
+
+    // Q^T fragments (B operand): lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8]
+    const int qt = qb * 3 + wave;
+    const int qrow = min(qt * 32 + r32, p.Tq - 1);
+    const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 16 + half * 8;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (d0 < dh) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
+        qf[ks] = __builtin_bit_cast(bf16x8, val);
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc = p.scale * LOG2E;
+    const bool ragged = (p.Tk & 31) != 0;
+
+    commit(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) fetch(kt + 1);
+        const char* sK = smem + (kt & 1) * BUF;
+        const char* sV = sK + KBYTES;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* krow = sK + r32 * KROW + half * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 32);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        if (ragged && !more) {                  // padded keys of the last tile: key of reg r = kt*32 + (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= p.Tk) s[r] = -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * sc);      // every tile holds >= 1 real key: m_new is finite
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_new));
+            psum += s[r];
+        }
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+        bf16x8 pf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
+            pf[j] = __builtin_bit_cast(bf16x8, pk);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const char* vrow = sV + (dt * 32 + r32) * VROW + (4 * half) * 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (16 * j) * 2);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (16 * j + 8) * 2);
+                const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j], o[dt], 0, 0, 0);
+            }
+        }
+        if (more) commit((kt + 1) & 1);         // that buffer was last read in tile kt-1: every wave is past its barrier
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qo = qt * 32 + r32;
+    if (qo < p.Tq) {
+        char* optr = p.out + (((int64_t)b * p.Tq + qo) * p.ldo + (int64_t)h * dh) * 2;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = dt * 32 + 8 * g + 4 * half;
+                if (d0 < dh) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+                    pk.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+                    *reinterpret_cast<uint2*>(optr + d0 * 2) = pk;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact fp32: one wave per query row; lanes = keys for QK^T, lanes = head dims for PV.
 constexpr int F32_MAXK = 8;     // keys per lane -> Tk <= 512
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
@@ -295,6 +468,16 @@ static int launch_bf16(const AttnParams& p, hipStream_t st) {
     return SPRC_OK;
 }
 
+template <int DHP>
+static int launch_stream(const AttnParams& p, hipStream_t st) {
+    constexpr int BUF = 32 * (DHP * 2 + 16) + DHP * 72;
+    const int nqb = ((p.Tq + 31) / 32 + 2) / 3;
+    const int bh = p.B * p.H;
+    hipLaunchKernelGGL(attn_stream_kernel<DHP>, dim3(bh * nqb), dim3(192), 2 * BUF, st, p, nqb, (bh % 8) == 0 ? 1 : 0);
+    SPRC_CHECK_LAUNCH("sprc_attention(bf16, streaming)");
+    return SPRC_OK;
+}
+
 }  // namespace sprc
 
 extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
@@ -314,6 +497,13 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
         SPRC_REQUIRE(((uintptr_t)a->q % 16) == 0 && ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0 &&
                          ((uintptr_t)a->out % 8) == 0, "sprc_attention(bf16): misaligned pointer");
         const bool small = a->Tq <= 128;
+        // long query axes without a key mask (the ViT blocks): streaming kernel, five small workgroups per CU
+        // (SPRC_ATTN_STREAM=0 keeps the resident-K/V kernel for A/B runs)
+        static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
+        if (stream && !small && a->key_mask == nullptr) {
+            if (a->head_dim <= 64) return launch_stream<64>(p, st);
+            return launch_stream<96>(p, st);
+        }
         // 257 tokens = 9 query tiles: nine waves (one tile each, the K / V staging shared by nine) beat eight waves of which
         // one carries two tiles: 209 -> 195 us per ViT-g layer (SPRC_ATTN_NINE=0 for the A/B)
         static const int nine = [] { const char* e = getenv("SPRC_ATTN_NINE"); return e ? atoi(e) : 1; }();

@@ -72,6 +72,21 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+typedef _Float16 f16_t;
+// 4 consecutive outputs of one row: 16 B (fp32) or 8 B (bf16 / fp16)
+template <typename OutT>
+__device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v) {
+    if constexpr (std::is_same<OutT, float>::value) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+    } else if constexpr (std::is_same<OutT, f16_t>::value) {
+        typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+        *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+}
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 template <> struct Frag<float> { typedef f32x4 type; };
@@ -227,13 +242,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         v[e] += rv[it][e];
                     }
                     if (!ok[it]) continue;
-                    OutT* dst = reinterpret_cast<OutT*>(p.C) + prow[it] * p.ldc + col;
-                    if constexpr (sizeof(OutT) == 2) {
-                        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-                        *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                    } else {
-                        *reinterpret_cast<f32x4*>(dst) = v;
-                    }
+                    store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + prow[it] * p.ldc + col, v);
                 }
             }
             return;
@@ -273,8 +282,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         }
                         if constexpr (ACT == SPRC_ACT_QUICKGELU) v = quick_gelu(v);
                         if (rrow != nullptr) v += rrow[col];
-                        if constexpr (sizeof(OutT) == 2) crow[col] = (__bf16)v;
-                        else crow[col] = v;
+                        crow[col] = (OutT)v;
                     }
             }
         }
@@ -342,7 +350,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const int a_off = (wr * TM * 32 + r32) * KT_BYTES, b_off = BM * KT_BYTES + (wc * TN * 32 + r32) * KT_BYTES;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
     const uint32_t c0 = (uint32_t)((half ^ sw) << 4);
-    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
+                        ((uintptr_t)p.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)p.bias % 16 == 0) && ((uintptr_t)p.resid % 16 == 0);
 
     if (nt > 0) {                                               // K-tile 0
         char* dst0 = smem + wave * 1024;
@@ -432,8 +441,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if constexpr (ACT == SPRC_ACT_GELU) v[e] = gelu_fast(v[e]);
         if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
         if (resid != nullptr) v[e] += resid[(int64_t)row * ldr + col + e];
-        if constexpr (sizeof(OutT) == 2) C[(int64_t)row * ldc + col + e] = (__bf16)v[e];
-        else C[(int64_t)row * ldc + col + e] = v[e];
+        C[(int64_t)row * ldc + col + e] = (OutT)v[e];
     }
 }
 
@@ -644,7 +652,8 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         asm volatile("" :: "v"(pf_sink));
     }
     if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
-    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0);
+    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
+                        ((uintptr_t)p.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)p.bias % 16 == 0) && ((uintptr_t)p.resid % 16 == 0);
     gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's stores have left the wave
@@ -830,6 +839,10 @@ static int launch(const GemmParams& p, hipStream_t st) {
 template <typename T>
 static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st) {
     if (a->max32) return launch<T, float, SPRC_ACT_NONE, true>(p, st);
+    if (a->out_dtype == SPRC_F16) {                     // residual-branch delta (validated by the caller: bf16 operands, plain epilogue)
+        if constexpr (sizeof(T) == 2) return launch<T, f16_t, SPRC_ACT_NONE, false>(p, st);
+        else { set_error("sprc_gemm: SPRC_F16 output needs bf16 operands"); return SPRC_EUNSUPPORTED; }
+    }
     const bool o16 = a->out_dtype == SPRC_BF16;
     switch (a->act) {
         case SPRC_ACT_NONE:
@@ -851,7 +864,9 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     SPRC_REQUIRE(a != nullptr, "sprc_gemm: null args");
     SPRC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "sprc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     SPRC_REQUIRE(a->dtype == SPRC_BF16 || a->dtype == SPRC_F32, "sprc_gemm: bad dtype %d", a->dtype);
-    SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32, "sprc_gemm: bad out_dtype %d", a->out_dtype);
+    SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32 || a->out_dtype == SPRC_F16, "sprc_gemm: bad out_dtype %d", a->out_dtype);
+    SPRC_REQUIRE(a->out_dtype != SPRC_F16 || (a->dtype == SPRC_BF16 && a->act == SPRC_ACT_NONE && !a->resid && !a->max32),
+                 "sprc_gemm: SPRC_F16 output takes bf16 operands and a plain (bias-only) epilogue");
     const int es = (int)dtype_size(a->dtype);
     SPRC_REQUIRE(((int64_t)a->K * es) % 128 == 0, "sprc_gemm: K=%d must be a multiple of %d", a->K, 128 / es);
     SPRC_REQUIRE((a->lda * es) % 16 == 0 && (a->ldw * es) % 16 == 0, "sprc_gemm: lda/ldw must be 16-byte multiples");

@@ -78,7 +78,22 @@ struct LnParams {
     const float* gamma; const float* beta; float eps;
     float* y32; int64_t ld32; sprc_rowmap ymap;
     void* y16; int64_t ld16;
+    const _Float16* add; int64_t ld_add;      // optional fp16 branch output added to x before the statistics
+    float* sum32; int64_t ld_sum;             // optional: x + add (the residual-stream update), may alias x
 };
+
+// r += add row (fp16, 8 B per lane and chunk)
+__device__ __forceinline__ void add_row_f16(RowRegs& r, const _Float16* a, int nch, int lane) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nch) {
+            const half4 h = reinterpret_cast<const half4*>(a)[i];
+            r.v[c].x += (float)h[0]; r.v[c].y += (float)h[1]; r.v[c].z += (float)h[2]; r.v[c].w += (float)h[3];
+        }
+    }
+}
 
 template <bool BF16>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams p) {
@@ -87,7 +102,12 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams
     if (row >= p.M) return;
     const int nch = p.D >> 2;
     RowRegs r;
-    load_row(r, p.x + map_row(p.xmap, row) * p.ldx, nch, lane);
+    const int64_t xr = map_row(p.xmap, row);
+    load_row(r, p.x + xr * p.ldx, nch, lane);
+    if (p.add != nullptr) {
+        add_row_f16(r, p.add + xr * p.ld_add, nch, lane);
+        if (p.sum32 != nullptr) store_row<false>(r, p.sum32 + xr * p.ld_sum, nullptr, nch, lane);
+    }
     layernorm_regs(r, nch, p.D, lane, p.gamma, p.beta, p.eps);
     const int64_t yr = map_row(p.ymap, row);
     store_row<BF16>(r, p.y32 ? p.y32 + yr * p.ld32 : nullptr,
@@ -224,10 +244,14 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
     SPRC_REQUIRE(a->ldx % 4 == 0 && (!a->y32 || a->ld32 % 4 == 0) && (!a->y16 || a->ld16 % 4 == 0),
                  "sprc_layernorm: leading dimensions must be multiples of 4");
     SPRC_REQUIRE(a->y32 || a->y16, "sprc_layernorm: no output");
-    LnParams p{a->M, a->D, a->x, a->ldx, a->xmap, a->gamma, a->beta, a->eps, a->y32, a->ld32, a->ymap, a->y16, a->ld16};
+    SPRC_REQUIRE(a->add16 == nullptr || (a->ld_add % 4 == 0 && ((uintptr_t)a->add16 % 8) == 0), "sprc_layernorm: add16 must be 8-byte aligned, ld_add % 4 == 0");
+    SPRC_REQUIRE(a->sum32 == nullptr || (a->add16 != nullptr && a->ld_sum % 4 == 0), "sprc_layernorm: sum32 needs add16 and ld_sum % 4 == 0");
+    LnParams p{a->M, a->D, a->x, a->ldx, a->xmap, a->gamma, a->beta, a->eps, a->y32, a->ld32, a->ymap, a->y16, a->ld16,
+               reinterpret_cast<const _Float16*>(a->add16), a->ld_add, a->sum32, a->ld_sum};
     const dim3 grid((a->M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
     ProfScope prof(SPRC_K_ROWOPS, (hipStream_t)s, 8.0 * a->M * (double)a->D,
-                   (double)a->M * a->D * (4.0 + (a->y32 ? 4.0 : 0.0) + (a->y16 ? (double)dtype_size(a->out_dtype) : 0.0)));
+                   (double)a->M * a->D * (4.0 + (a->y32 ? 4.0 : 0.0) + (a->y16 ? (double)dtype_size(a->out_dtype) : 0.0) +
+                                          (a->add16 ? 2.0 : 0.0) + (a->sum32 ? 4.0 : 0.0)));
     if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, (hipStream_t)s, p);
     SPRC_CHECK_LAUNCH("sprc_layernorm");

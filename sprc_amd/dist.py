@@ -6,7 +6,8 @@ rank r encodes and keeps the contiguous slice [r*n_local, (r+1)*n_local) residen
 query is fused on the rank that owns its reference image (its raw embeds, 1.45 MB, never move).
 The only exchange steps are
   1. all_gather of the fused query vectors  [nq_local, 256] fp32   (nq*1 KiB in total),
-  2. all_gather of per-shard top-k          [nq, k] (fp32 score, int32 global index) = nq*k*8 B / rank,
+  2. ONE all_gather of per-shard top-k      [nq, k] (fp32 score, int32 global index) = nq*k*8 B / rank, carrying in
+     the same payload the scores of the <= 7 listed items per query (CIRR target / subset members) their owner holds,
 followed by a k*R-candidate merge on every rank.  Both payloads are tiny (latency-bound); no
 all-reduce, no ring over the feature tensors.  Because every comparison uses the integer key
 (fl32(1 - sim), global index), the merged result is bit-identical to the single-GPU ranking.
@@ -52,13 +53,31 @@ def owner_of(index: torch.Tensor, n_total: int, world: int) -> torch.Tensor:
     return torch.where(idx < big, idx // (base + 1), small_owner).to(torch.int64)
 
 
+def offsets_of(counts) -> torch.Tensor:
+    """[world+1] exclusive prefix sums of per-rank shard sizes (general form of `shard_bounds`: a rank's slice may have
+    lost items its dataset failed to load, data_utils.py:191-192)."""
+    c = torch.as_tensor(list(counts), dtype=torch.int64)
+    return torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(c, 0)])
+
+
+def owner_from_offsets(index: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """Rank whose slice [offsets[r], offsets[r+1]) holds each global gallery index."""
+    return torch.searchsorted(offsets[1:].contiguous(), index.to(torch.int64).contiguous(), right=True)
+
+
 def _all_gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
-    """all_gather of equally-shaped tensors along dim 0 (one collective)."""
+    """all_gather of equally-shaped tensors along dim 0 (one collective).  Over RCCL the payload stays on the device; with
+    the gloo backend (CPU tests, and the oversubscribed N-ranks-on-one-GPU test mode) device tensors are staged through
+    the host."""
     world = dist.get_world_size(group)
-    out = torch.empty((world * x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous(), group=group) if x.is_cuda else \
-        dist.all_gather(list(out.chunk(world, dim=0)), x.contiguous(), group=group)
-    return out
+    if x.is_cuda and dist.get_backend(group) != "gloo":
+        out = torch.empty((world * x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+        return out
+    h = x.detach().contiguous().cpu()
+    out = torch.empty((world * h.shape[0], *h.shape[1:]), dtype=h.dtype)
+    dist.all_gather(list(out.chunk(world, dim=0)), h, group=group)
+    return out.to(x.device)
 
 
 class ShardedRanker:
@@ -68,22 +87,41 @@ class ShardedRanker:
                  group=None):
         self.feats, self.base, self.sim_fn, self.topk_fn, self.group = local_feats, int(index_base), sim_fn, topk_fn, group
 
-    def rank(self, fusion_local: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def rank(self, fusion_local: torch.Tensor, k: int, listed: Optional[torch.Tensor] = None,
+             select: Optional[torch.Tensor] = None):
         """fusion_local [nq_local,E] (same nq_local on every rank; pad with zero rows if ragged) ->
-        (sim[nq,k], global idx[nq,k]) for ALL nq = world*nq_local queries, identical on every rank."""
+        (sim[nq,k], global idx[nq,k]) for the nq queries, identical on every rank.
+
+        select: optional int64 [nq] positions in the gathered [world*nq_local] fusion rows (drops padding rows and
+                puts the queries in the caller's order; default = all gathered rows in rank order).
+        listed: optional [nq,L] GLOBAL gallery indices (-1 = none) whose scores the caller needs besides the top-k
+                (CIRR subset members / targets): the owner of each contributes its score in the SAME all_gather as
+                the per-shard top-k; returns a third tensor listed_sim[nq,L] (-inf where -1)."""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         fusion = _all_gather_rows(fusion_local, self.group) if world > 1 else fusion_local     # exchange 1
-        sim = self.sim_fn(fusion, self.feats)
+        if select is not None:
+            fusion = fusion.index_select(0, select.to(fusion.device))
+        nq, n_local = fusion.shape[0], self.feats.shape[0]
+        sim = self.sim_fn(fusion.contiguous(), self.feats)
         vals, idx = self.topk_fn(sim, k, None, self.base)
+        lv = None
+        if listed is not None:                                                                  # scores of the listed items this rank owns
+            col = listed.to(device=sim.device, dtype=torch.int64) - self.base
+            own = (col >= 0) & (col < n_local)
+            lv = torch.where(own, sim.gather(1, col.clamp(0, max(n_local - 1, 0))) if n_local else torch.zeros_like(col, dtype=sim.dtype),
+                             torch.full(col.shape, float("-inf"), dtype=sim.dtype, device=sim.device))
         if world == 1:
-            return vals, idx
-        nq = fusion.shape[0]
-        cv = _all_gather_rows(vals.t().contiguous(), self.group)                                # exchange 2: [world*k, nq]
-        ci = _all_gather_rows(idx.t().contiguous(), self.group)
-        cand_v = cv.view(world, k, nq).permute(2, 0, 1).reshape(nq, world * k).contiguous()
-        cand_i = ci.view(world, k, nq).permute(2, 0, 1).reshape(nq, world * k).contiguous()
+            return (vals, idx) if listed is None else (vals, idx, lv)
+        # exchange 2: ONE all_gather of [nq, k (score bits) + k (global index) + L (listed score bits)] int32 per rank
+        parts = [vals.contiguous().view(torch.int32), idx] + ([lv.contiguous().view(torch.int32)] if lv is not None else [])
+        got = _all_gather_rows(torch.cat(parts, dim=1).contiguous(), self.group).view(world, nq, -1)
+        cand_v = got[:, :, :k].permute(1, 0, 2).reshape(nq, world * k).contiguous().view(torch.float32)
+        cand_i = got[:, :, k:2 * k].permute(1, 0, 2).reshape(nq, world * k).contiguous()
         # unused slots (shard smaller than k) carry sim=-inf / idx=-1: give them the worst possible key
         cand_i = torch.where(cand_i < 0, torch.full_like(cand_i, 2**31 - 1), cand_i)
         mv, mi = self.topk_fn(cand_v, k, cand_i, 0)
         mi = torch.where(torch.isinf(mv) & (mv < 0), torch.full_like(mi, -1), mi)
-        return mv, mi
+        if listed is None:
+            return mv, mi
+        ls = got[:, :, 2 * k:].contiguous().view(torch.float32).max(dim=0).values               # exactly one owner per item
+        return mv, mi, ls

@@ -14,7 +14,7 @@ import torch
 from . import _lib as L
 from .config import SprcConfig
 
-_TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16}
+_TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16, L.SPRC_F16: torch.float16}
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -78,7 +78,7 @@ def gemm_pair(A: torch.Tensor, W0: torch.Tensor, W1: torch.Tensor, bias0, bias1,
 
 
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype: int, want32=True, want16=True,
-              xmap=None, ymap=None, M=None, y32=None, y16=None):
+              xmap=None, ymap=None, M=None, y32=None, y16=None, add16=None, sum32=None):
     lib = L.load()
     Mx, D = x.shape
     M = Mx if M is None else M
@@ -92,6 +92,11 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype: int, want32=T
     a.gamma, a.beta, a.eps = gamma.data_ptr(), beta.data_ptr(), eps
     a.y32, a.ld32, a.ymap = _ptr(y32), D, ymap or rowmap()
     a.y16, a.ld16 = _ptr(y16), D
+    if add16 is not None:                        # fused residual add: LN(x + add16); sum32 (optional) <- x + add16
+        assert add16.dtype == torch.float16 and add16.stride(-1) == 1
+        a.add16, a.ld_add = add16.data_ptr(), add16.stride(0)
+        if sum32 is not None:
+            a.sum32, a.ld_sum = sum32.data_ptr(), sum32.stride(0)
     L.check(lib.sprc_layernorm(C.byref(a), _stream()), "sprc_layernorm")
     return y32, y16
 

@@ -12,7 +12,7 @@ full sort and no nq x N host traffic.
 from __future__ import annotations
 
 from operator import itemgetter
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -34,28 +34,84 @@ def collate_fn(batch: list):
     return torch.utils.data.dataloader.default_collate(batch)
 
 
-def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, batch_size: int = 64, num_workers: int = 2):
-    """-> ((feats[N,32,256], raw[N,257,D]), names[N])   (src/utils.py:46-77)"""
+class RawStore:
+    """`index_features[1]` when raw ViT embeddings are kept for a SUBSET of the gallery (the
+    protocol returns raw[N,257,D] fp32 for every image, 1.45 MB each -- 3.3 GB for CIRR val, 1.4 TB for a 1 M gallery --
+    but only the images some query uses as its reference are ever looked up, validate_blip.py:377,395-399).
+    Indexable by gallery position and iterable in gallery order like the stacked tensor (rows that were not kept
+    yield None), so `dict(zip(index_names, index_features[1]))` keeps working."""
+
+    def __init__(self, n: int, rows: Dict[int, torch.Tensor]):
+        self.n, self.rows = int(n), rows
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        i = int(i)
+        if i < 0:
+            i += self.n
+        return self.rows.get(i)
+
+    def __iter__(self):
+        return (self.rows.get(i) for i in range(self.n))
+
+    def to(self, *a, **k):
+        return RawStore(self.n, {i: r.to(*a, **k) for i, r in self.rows.items()})
+
+    def cpu(self):
+        return self.to("cpu")
+
+    @property
+    def kept(self) -> int:
+        return len(self.rows)
+
+    def nbytes(self) -> int:
+        return sum(r.numel() * r.element_size() for r in self.rows.values())
+
+
+def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, batch_size: int = 64, num_workers: int = 2,
+                                keep_raw=True, raw_dtype: Optional[torch.dtype] = None):
+    """-> ((feats[N,32,256], raw), names[N])   (src/utils.py:46-77)
+
+    keep_raw=True (the reference's behaviour): raw = the stacked [N,257,D] fp32 tensor.
+    keep_raw=<collection of names> (or False): raw = a `RawStore` holding the embeddings of those images only
+    (`raw_dtype=torch.bfloat16` halves them; they are cast back to fp32 when a query is fused)."""
     loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True, collate_fn=collate_fn)
     feats, raws, names = [], [], []
     split = getattr(dataset, "split", "")
     print(f"extracting {type(dataset).__name__} {split} index features")
     dev = blip_model.device
+    subset = keep_raw is not True
+    wanted = set() if keep_raw in (False, None) else (set(keep_raw) if subset else None)
+    rows: Dict[int, torch.Tensor] = {}
     for batch_names, images in tqdm(loader):
         images = images.to(dev, non_blocking=True)
         f, r = blip_model.extract_target_features(images, mode="mean")
+        if raw_dtype is not None:
+            r = r.to(raw_dtype)
         if save_memory:
             f, r = f.cpu(), r.cpu()
         feats.append(f)
-        raws.append(r)
+        if subset:
+            for j, n in enumerate(batch_names):
+                if n in wanted:
+                    rows[len(names) + j] = r[j].clone()
+        else:
+            raws.append(r)
         names.extend(batch_names)
+    if subset:
+        return (torch.vstack(feats), RawStore(len(names), rows)), names
     return (torch.vstack(feats), torch.vstack(raws)), names
 
 
 def _stack_refs(name_to_feat: Dict[str, torch.Tensor], names: Sequence[str]) -> torch.Tensor:
+    missing = [n for n in names if name_to_feat.get(n) is None]
+    if missing:
+        raise KeyError(f"no raw embeddings kept for reference image(s) {missing[:3]}: pass their names in `keep_raw`")
     if len(names) == 1:
-        return name_to_feat[names[0]].unsqueeze(0)
-    return torch.stack(itemgetter(*names)(name_to_feat))
+        return name_to_feat[names[0]].unsqueeze(0).float()
+    return torch.stack(itemgetter(*names)(name_to_feat)).float()
 
 
 # ---- CIRR validation ---------------------------------------------------------------------------------
@@ -95,7 +151,7 @@ def cirr_metrics_from_sim(sim: torch.Tensor, ref_idx, tgt_idx, group_idx) -> Tup
     rank_t = r_t - (r_ref < r_t)                                        # validate_blip.py:258-261: drop the reference
     in_group = (group_idx == tgt_idx[:, None]).sum(1)
     assert (in_group == 1).all(), "target must appear exactly once among the group members"     # :273-274
-    member_ok = group_idx != ref_idx[:, None]
+    member_ok = (group_idx != ref_idx[:, None]) & (group_idx >= 0)     # a member missing from the gallery never matches (:268-271)
     pos_in_group = ((r_g < r_t[:, None]) & member_ok).sum(1)            # :268-271
     return (_pct(pos_in_group < 1), _pct(pos_in_group < 2), _pct(pos_in_group < 3),
             _pct(rank_t < 1), _pct(rank_t < 5), _pct(rank_t < 10), _pct(rank_t < 50))

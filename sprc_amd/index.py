@@ -6,7 +6,9 @@ The reference re-encodes the whole gallery on every run (`src/utils.py:46-77` re
     feats      [N, 32, 256]  fp32   unit-norm Q-Former query features (what `inference` ranks against)
     raw        [N, 257, D]   fp32   optional: ViT embeddings of the images that can be *reference* images of a query
                                     (CIRR/FashionIQ take references from the gallery itself); omitted for pure galleries
-    metadata   names (JSON list, row order), backbone, dtype the features were computed in, format version
+    metadata   names (JSON list, row order), backbone, dtype the features were computed in, format version,
+               checkpoint_sha256 = fingerprint of the state dict that produced the features (blip_validate refuses a store
+               written by another checkpoint)
 
 Loading is a plain mmap + one host-to-device copy; ranking from a loaded store is bit-identical to ranking from the
 tensors it was saved from (tests/test_host.py, tests/test_fullsize_gpu.py).
@@ -23,7 +25,7 @@ FORMAT = "sprc-index-1"
 
 
 def save_index(path, feats: torch.Tensor, names: Sequence[str], raw: Optional[torch.Tensor] = None, backbone: str = "",
-               compute_dtype: str = "") -> None:
+               compute_dtype: str = "", checkpoint_sha256: str = "") -> None:
     from safetensors.torch import save_file
     if feats.dim() != 3 or feats.shape[1] != 32:
         raise ValueError(f"feats must be [N,32,E], got {tuple(feats.shape)}")
@@ -34,7 +36,8 @@ def save_index(path, feats: torch.Tensor, names: Sequence[str], raw: Optional[to
     tensors = {"feats": feats.detach().to("cpu", torch.float32).contiguous()}
     if raw is not None:
         tensors["raw"] = raw.detach().to("cpu", torch.float32).contiguous()
-    meta = {"format": FORMAT, "names": json.dumps(list(names)), "backbone": backbone, "compute_dtype": compute_dtype}
+    meta = {"format": FORMAT, "names": json.dumps(list(names)), "backbone": backbone, "compute_dtype": compute_dtype,
+            "checkpoint_sha256": checkpoint_sha256}
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
     save_file(tensors, str(path), metadata=meta)

@@ -132,17 +132,60 @@ def iter_state_dict(cfg: SprcConfig, seed: int = 0, device: str = "cpu") -> Iter
         yield name, _draw(name, shape, kind, seed, device)
 
 
-def make_state_dict(cfg: SprcConfig, seed: int = 0, device: str = "cpu") -> Dict[str, torch.Tensor]:
-    """Seeded random state dict with the reference's key names (fp32)."""
-    sd = dict(iter_state_dict(cfg, seed, device))
-    sd["temp"] = torch.tensor(0.07, device=device)          # align_prompt.py:84 (unused by inference)
+PLANT_RANK = 8          # rank of the planted ITC heads: cosines live in an 8-dim subspace -> scores spread over ~ +-0.8
+
+
+def plant_structure(sd: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Planted-structure variant of a random state dict.  Plain random-init weights give nearly
+    uniform similarities (0.02 .. 0.09, neighbour gaps of 1e-4: Recall@K is decided by noise).  Here
+      * vision_proj / text_proj share a rank-8 output subspace (W = U A with U [256,8] orthonormal), so the max-cosine
+        scores of a gallery row spread over more than 1.0 with a median neighbour gap of 1e-2;
+      * the paths that carry image content and text into the features are amplified (cross-attention x6, word embeddings
+        x5, every Q-Former linear x3) and the learned query tokens damped (x0.2), so the scores depend on the inputs.
+    In place; CPU tensors only (parity runs)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(777 + seed)
+    E, H = sd["vision_proj.weight"].shape
+    U = torch.linalg.qr(torch.randn((E, PLANT_RANK), generator=g, dtype=torch.float32))[0]
+    for k in list(sd):
+        if not k.startswith("Qformer.") or not k.endswith("weight") or "LayerNorm" in k:
+            continue
+        if "crossattention" in k:
+            sd[k] = sd[k] * 6.0
+        elif "word_embeddings" in k:
+            sd[k] = sd[k] * 5.0
+        elif "embeddings" not in k:
+            sd[k] = sd[k] * 3.0
+    sd["vision_proj.weight"] = (U @ (torch.randn((PLANT_RANK, H), generator=g) * 0.2)).contiguous()
+    sd["text_proj.weight"] = (U @ (torch.randn((PLANT_RANK, H), generator=g) * 0.2)).contiguous()
+    sd["vision_proj.bias"] = sd["vision_proj.bias"] * 0.1
+    sd["text_proj.bias"] = sd["text_proj.bias"] * 0.1
+    sd["query_tokens"] = sd["query_tokens"] * 0.2
     return sd
 
 
-def make_images(n: int, seed: int = 0, image: int = 224) -> torch.Tensor:
+def make_state_dict(cfg: SprcConfig, seed: int = 0, device: str = "cpu", planted: bool = False) -> Dict[str, torch.Tensor]:
+    """Seeded random state dict with the reference's key names (fp32); planted=True: see `plant_structure`."""
+    sd = dict(iter_state_dict(cfg, seed, device))
+    sd["temp"] = torch.tensor(0.07, device=device)          # align_prompt.py:84 (unused by inference)
+    if planted:
+        if device != "cpu":
+            raise ValueError("planted weights are drawn on the CPU (reproducible against the golden fixtures)")
+        plant_structure(sd, seed)
+    return sd
+
+
+def make_images(n: int, seed: int = 0, image: int = 224, planted: bool = False) -> torch.Tensor:
+    """N(0,1) pixels; planted=True: 0.8 * (random mixture of 8 basis images) + 0.4 * noise, so that images differ along a
+    few shared directions instead of being 150k-dimensional white noise."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
-    return torch.randn((n, 3, image, image), generator=g, dtype=torch.float32)
+    if not planted:
+        return torch.randn((n, 3, image, image), generator=g, dtype=torch.float32)
+    basis = torch.randn((8, 3, image, image), generator=g, dtype=torch.float32)
+    coef = torch.randn((n, 8), generator=g, dtype=torch.float32)
+    noise = torch.randn((n, 3, image, image), generator=g, dtype=torch.float32)
+    return torch.einsum("nk,kchw->nchw", coef, basis).mul_(0.8).add_(noise.mul_(0.4))
 
 
 def make_queries(nq: int, n_gallery: int, seed: int = 1, max_len: int = 32,

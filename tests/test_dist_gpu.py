@@ -1,0 +1,125 @@
+"""Multi-rank GPU tests on ONE device (the GPU box has a single MI355X): two processes share cuda:0, every kernel on the
+path is the HIP library's, and the two tiny exchanges of sprc_amd/dist.py go through gloo (RCCL refuses two ranks on one
+device; on an 8-GPU node the same code runs over RCCL with one rank per GPU).
+
+* sharded CIRR evaluation (sprc_amd/dist_eval.py) == the single-process harness: identical score bits, identical top-k,
+  identical Recall@K / subset recall / submission dicts;
+* `bench.py --gpus 2` outside a launcher spawns two ranks itself and prints ONE line with n_gpus = 2.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+
+import _dist_case as DC  # noqa: E402
+from sprc_amd import synth  # noqa: E402
+from sprc_amd.config import get_config  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _model(case):
+    from sprc_amd.model import Blip2QformerCirAlignPrompt
+    cfg = get_config("pretrain", vit_depth=2)
+    model = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=32)
+    assert not model.load_state_dict(synth.make_state_dict(cfg, seed=11), strict=False).missing_keys
+    model = model.to(DEV)
+    model.tokenizer = DC.FakeTokenizer(case["ids"], case["mask"])
+    return model
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from sprc_amd import dist_eval as DE
+    from sprc_amd import engine as E
+    case = DC.build(0)
+    model = _model(case)
+    gallery = DC.Gallery(case["images"])
+    rel = DC.Relative(case["ref"], case["tgt"], case["groups"])
+    rec = {}
+
+    def sim_fn(fusion, feats):
+        rec["sim"] = E.sim_max(fusion.contiguous(), feats.contiguous())
+        return rec["sim"]
+
+    cirr = DE.compute_cirr_val_metrics_sharded(rel, gallery, model, DC.TXT, num_workers=0, gallery_batch_size=16, sim_fn=sim_fn)
+    q = DE.cirr_val_queries(rel, DC.TXT)
+    shard = DE.encode_gallery_shard(gallery, model, reference_names=q.ref_names, num_workers=0, batch_size=16)
+    top_v, top_i, _ = DE.sharded_rank(shard, q, model, sim_fn=sim_fn)
+    top, sub = DE.generate_cirr_test_dicts_sharded(DC.RelativeTest(case["ref"], case["tgt"], case["groups"]), gallery, model,
+                                                   DC.TXT, num_workers=0, gallery_batch_size=16)
+    torch.cuda.synchronize()
+    out[rank] = dict(cirr=cirr, top=top, sub=sub, sim=rec["sim"].cpu().numpy(), top_v=top_v.cpu().numpy(),
+                     top_i=top_i.cpu().numpy(), n_raw=len(shard.raw), n_local=shard.feats.shape[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_harness():
+    from sprc_amd import engine as E
+    from sprc_amd import harness as H
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        res = {r: dict(out[r]) for r in range(world)}
+    case = DC.build(0)
+    model = _model(case)
+    gallery = DC.Gallery(case["images"])
+    (feats, raw), names = H.extract_index_blip_features(gallery, model, batch_size=16, num_workers=0)
+    rel = DC.Relative(case["ref"], case["tgt"], case["groups"])
+    want_cirr = H.compute_cirr_val_metrics(rel, model, (feats, raw), names, DC.TXT)
+    sim_1, *_ = H.generate_cirr_val_predictions(model, rel, names, (feats, raw), DC.TXT, num_workers=0)
+    want_top, want_sub = H.generate_cirr_test_dicts(DC.RelativeTest(case["ref"], case["tgt"], case["groups"]), model, (feats, raw),
+                                                    names, DC.TXT)
+    want_v, want_i = E.topk(sim_1.contiguous(), 51)
+    sim_sharded = np.concatenate([res[r]["sim"] for r in range(world)], axis=1)
+    assert sum(res[r]["n_local"] for r in range(world)) == len(names) == DC.N_IMG - 1
+    # the exact-fp32 engine is batch-invariant: the shards' score blocks are the single-process scores, bit for bit
+    np.testing.assert_array_equal(sim_sharded, sim_1.cpu().numpy())
+    for r in range(world):
+        np.testing.assert_array_equal(res[r]["top_i"], want_i.cpu().numpy())
+        np.testing.assert_array_equal(res[r]["top_v"], want_v.cpu().numpy())
+        assert res[r]["cirr"] == want_cirr
+        assert res[r]["top"] == want_top and res[r]["sub"] == want_sub
+        assert res[r]["n_raw"] < res[r]["n_local"]            # raw embeddings only for local reference images
+
+
+def test_bench_gpus2_spawns_two_ranks():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["sharding"] == "gallery-sharded x2"
+    ngpu = torch.cuda.device_count()
+    assert ("gloo" in d["config"]["backend"]) == (ngpu < 2)
+    assert abs(d["value"] - 2 * d["config"]["batch"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.sprc_version() == 1
+    assert lib.sprc_version() == _lib.ABI_VERSION == int(re.search(r"#define SPRC_ABI_VERSION (\d+)", header).group(1))
     assert isinstance(lib.sprc_last_error(), bytes)
 
 

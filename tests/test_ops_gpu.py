@@ -239,6 +239,55 @@ def test_layernorm(D, eps):
     torch.testing.assert_close(xm.cpu(), ref2, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(257 * 2, 1408, 1408), (2300, 1408, 704), (4096 + 100, 1408, 6144), (233 * 32, 768, 3072), (70, 96, 64)])
+def test_gemm_f16_delta_output(M, N, K):
+    """SPRC_F16 output (a residual-branch delta): the fp32 result rounded once to fp16 -- every tile path (128x128, 256x256
+    anti-phase, peeled remainder, split-K remainder with caller scratch)."""
+    A, W, b = _bf(_rand((M, K), 61)), _bf(_rand((N, K), 62, 0.03)), _rand((N,), 63)
+    ref = A.double() @ W.double().t() + b.double()
+    scratch = torch.empty(8 * 128 * N, dtype=torch.float32, device=DEV)
+    out = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), out_dtype=L.SPRC_F16, scratch=scratch)
+    assert out.dtype == torch.float16
+    f32 = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), out_dtype=L.SPRC_F32, scratch=scratch)
+    assert torch.equal(out.cpu(), f32.cpu().to(torch.float16))                # same accumulation, one fp16 rounding
+    torch.testing.assert_close(out.cpu().double(), ref, atol=2e-3 * math.sqrt(K / 64) + 2e-3, rtol=1e-3)
+    with pytest.raises(L.SprcError):                                           # fp16 output carries no residual / activation
+        E.gemm(A.to(DEV), W.to(DEV), resid=f32, out_dtype=L.SPRC_F16)
+    with pytest.raises(L.SprcError):
+        E.gemm(A.to(DEV), W.to(DEV), act=L.ACT_GELU, out_dtype=L.SPRC_F16)
+
+
+@pytest.mark.parametrize("D,eps", [(1408, 1e-6), (768, 1e-12)])
+def test_layernorm_fused_residual_add(D, eps):
+    """LN(x + add16) with the sum written back over x (pre-LN residual update) and the bf16 result written over add16
+    (the aliasing models.hip uses); row-mapped variant for the Q-Former's query/text row groups."""
+    M = 131
+    x, d = _rand((M, D), 70, 2.0), (_rand((M, D), 71) * 0.5).to(torch.float16)
+    g, b = _rand((D,), 72) * 0.1 + 1, _rand((D,), 73) * 0.1
+    s_ref = x + d.float()                                                       # one fp32 add per element: exact reference
+    y_ref = torch.nn.functional.layer_norm(s_ref.double(), (D,), g.double(), b.double(), eps)
+    xd, dd = x.to(DEV), d.to(DEV)
+    buf16 = dd.clone().view(torch.bfloat16)                                     # y16 aliases add16 (2-byte elements, same rows)
+    y32, y16 = E.layernorm(xd, g.to(DEV), b.to(DEV), eps, L.SPRC_BF16, y16=buf16, add16=buf16.view(torch.float16), sum32=xd)
+    assert torch.equal(xd.cpu(), s_ref)                                         # x <- x + add16, bit-exact
+    torch.testing.assert_close(y32.cpu().double(), y_ref, atol=1e-5, rtol=1e-5)
+    assert torch.equal(buf16.cpu(), y32.cpu().to(torch.bfloat16))
+    # without sum32: x untouched (post-LN BERT form: a = LN(dense + x))
+    xd2 = x.to(DEV)
+    y32b, _ = E.layernorm(xd2, g.to(DEV), b.to(DEV), eps, L.SPRC_BF16, add16=dd)
+    assert torch.equal(xd2.cpu(), x) and torch.equal(y32b.cpu(), y32.cpu())
+    # row maps: rows [32:64] of every 64-row group
+    xm, dm = _rand((3 * 64, D), 74).to(DEV), (_rand((3 * 64, D), 75) * 0.3).to(torch.float16).to(DEV)
+    mp = E.rowmap(32, 64, 32)
+    out32 = torch.zeros((3 * 64, D), device=DEV)
+    E.layernorm(xm, g.to(DEV), b.to(DEV), eps, L.SPRC_F32, want16=False, xmap=mp, ymap=mp, M=3 * 32, y32=out32, add16=dm)
+    sel = torch.cat([torch.arange(gp * 64 + 32, gp * 64 + 64) for gp in range(3)])
+    want = torch.nn.functional.layer_norm((xm.cpu() + dm.cpu().float())[sel], (D,), g, b, eps)
+    torch.testing.assert_close(out32.cpu()[sel], want, atol=1e-5, rtol=1e-5)
+    rest = torch.ones(3 * 64, dtype=torch.bool); rest[sel] = False
+    assert torch.all(out32.cpu()[rest] == 0)
+
+
 def _attn_ref(q, k, v, scale, mask=None):
     s = (q.double() @ k.double().transpose(-1, -2)) * scale
     if mask is not None:
