@@ -14,6 +14,7 @@ Files written:
   tests/golden/full_clip.npz   full depth ViT-L (23 blocks), 2 images, 3 queries   (--full)
   tests/golden/planted_eva.npz planted-structure weights (scores spread > 1.0), depth-4 ViT-g, 160 gallery x 72 queries:
                                scores, planned targets, the reference's own metrics / submission dicts on them
+  tests/golden/rerank_eva.npz  stage-2 rerank: the reference's Blip2QformerCirRerank.inference_rerank on 3 queries x 4 candidates
   tests/golden/metrics.json    reference compute_cirr_val_metrics / compute_fiq_val_metrics /
                                generate_cirr_test_dicts on synthetic sims (with engineered ties)
   tests/golden/captions.json   reference BlipCaptionProcessor + FashionIQ caption composition
@@ -270,6 +271,29 @@ def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int =
           f"median gap {np.median(gaps):.1e} gaps<1e-5: {int((gaps < 1e-5).sum())}/{gaps.size}  cirr {[round(x, 2) for x in cirr]} fiq {fiq}")
 
 
+def rerank_goldens(out: Path, seed: int = 2):
+    """Stage-2 rerank fixture (N2): the REFERENCE's Blip2QformerCirRerank.inference_rerank (blip2_qformer_cir_rerank.py:
+    399-445) on 3 queries x 4 candidates (depth-2 ViT-g, full Q-Former), plus the reference's generate_cirr_test_dicts with
+    rerank=True on a fake model that returns those probabilities."""
+    cfg = get_config("pretrain", vit_depth=2)
+    sd = synth.make_state_dict(cfg, seed=seed)
+    model = ref_import.build_reference_model(cfg, sd, variant="rerank")
+    n_img, n_q, T = 6, 3, 4
+    images = synth.make_images(n_img, seed=seed)
+    ids, mask, ref = synth.make_queries(n_q, n_img, seed=seed + 1)
+    cand = torch.tensor([[(int(ref[q]) + 1 + t) % n_img for t in range(T)] for q in range(n_q)])
+    with torch.no_grad():
+        _, raw = model.extract_target_features(images, mode="mean")
+        model.tokenizer.set_next(ids, mask)
+        prob = model.inference_rerank(raw[ref], raw[cand.reshape(-1)], ["caption"] * n_q)
+        model.tokenizer.set_next(ids[:1], mask[:1])
+        prob_one = model.inference_rerank(raw[ref[:1]], raw[cand[0]], ["caption"])          # the B == 1 branch (:404-406)
+    np.savez_compressed(out, model_type="pretrain", vit_depth=2, seed=seed, n_img=n_img, n_q=n_q, T=T,
+                        image_probe=_np(images[:, :, 0, :4]), input_ids=ids.numpy(), attention_mask=mask.numpy(),
+                        ref_index=ref.numpy(), cand_index=cand.numpy(), prob=_np(prob), prob_one=_np(prob_one))
+    print(f"wrote {out}: prob {prob.numpy().round(4).tolist()}")
+
+
 def caption_goldens(out: Path):
     import importlib
     import types
@@ -325,6 +349,8 @@ def main():
         model_goldens("pretrain", 2, n_img=4, n_q=6, out=GOLD / "tiny_eva.npz")
     if want("tiny_clip"):
         model_goldens("pretrain_vitL", 2, n_img=3, n_q=4, out=GOLD / "tiny_clip.npz")
+    if want("rerank"):
+        rerank_goldens(GOLD / "rerank_eva.npz")
     if want("planted"):
         planted_goldens(GOLD / "planted_eva.npz")
     if a.full and want("full_eva"):

@@ -113,7 +113,7 @@ def install_shims() -> None:
     _installed = True
 
 
-def build_reference_model(cfg, state_dict, eval_mode: bool = True):
+def build_reference_model(cfg, state_dict, eval_mode: bool = True, variant: str = "align_prompt"):
     """Construct the reference's Blip2QformerCirAlignPrompt (CPU, fp32) with `cfg` depths and load
     `state_dict` into it.  Returns the nn.Module.  Network-only constructors are replaced by the
     same constructor calls without the download (SURVEY.md 8(c) shim 8)."""
@@ -171,13 +171,20 @@ def build_reference_model(cfg, state_dict, eval_mode: bool = True):
         torch.finfo(torch.float32).min
     qf.BertLMHeadModel.from_pretrained = classmethod(lambda cls, name, config=None, **k: cls(config))
 
-    ap = importlib.import_module("lavis.models.blip2_models.blip2_qformer_cir_align_prompt")
     vit_model = "eva_clip_g" if v.kind == "eva_g" else "clip_L"
     torch.manual_seed(0)
-    model = ap.Blip2QformerCirAlignPrompt(vit_model=vit_model, vit_precision="fp32")
+    if variant == "rerank":            # the stage-2 model class (blip2_qformer_cir_rerank.py): same trunk + a frozen copy it
+        rr = importlib.import_module("lavis.models.blip2_models.blip2_qformer_cir_rerank")      # never uses at inference
+        model = rr.Blip2QformerCirRerank(vit_model=vit_model, vit_precision="fp32")
+        allowed_missing = ("Qformer.cls.", "Qformer.bert.embeddings.position_ids", "Fformer.", "query_tokens_f", "vision_proj_f.", "text_proj_f.")
+    else:
+        ap = importlib.import_module("lavis.models.blip2_models.blip2_qformer_cir_align_prompt")
+        model = ap.Blip2QformerCirAlignPrompt(vit_model=vit_model, vit_precision="fp32")
+        allowed_missing = ("Qformer.cls.", "itm_head.", "Qformer.bert.embeddings.position_ids")
     msg = model.load_state_dict(state_dict, strict=False)
-    allowed_missing = ("Qformer.cls.", "itm_head.", "Qformer.bert.embeddings.position_ids")
     bad = [k for k in msg.missing_keys if not k.startswith(allowed_missing)]
+    if variant == "rerank":
+        msg.unexpected_keys[:] = [k for k in msg.unexpected_keys if k != "prompt_tokens"]
     if bad or msg.unexpected_keys:
         raise RuntimeError(f"state-dict mismatch: missing={bad[:8]} unexpected={msg.unexpected_keys[:8]}")
     model = model.float()

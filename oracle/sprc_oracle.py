@@ -252,6 +252,27 @@ def inference(sd: SD, cfg, reference_embeds: Tensor, target_feats: Tensor, input
     return similarity(fusion, target_feats)
 
 
+def inference_rerank(sd: SD, cfg, reference_embeds: Tensor, target_embeds: Tensor, input_ids: Tensor,
+                     attention_mask: Tensor) -> Tensor:
+    """`Blip2QformerCirRerank.inference_rerank` blip2_qformer_cir_rerank.py:399-445 with pre-tokenised text (N2).
+
+    reference_embeds [B,257,D]; target_embeds [B*T,257,D] (T candidates per query, query-major); ids/mask [B,32].
+    Every (query, candidate) pair runs the Q-Former ONCE in call shape (ii) with the 514 encoder tokens
+    cat(reference, candidate) (:430-437); itm_head on the 32 query rows, mean over them, softmax over the two
+    classes, probability of class 1 ("match") -> [B*T]."""
+    B, BT = reference_embeds.shape[0], target_embeds.shape[0]
+    T = BT // B if B > 1 else BT                                             # :404-407
+    ref = reference_embeds.repeat_interleave(T, dim=0)                       # 'b l d -> (b t) l d'
+    ids = input_ids.repeat_interleave(T, dim=0)
+    atts = attention_mask.repeat_interleave(T, dim=0)
+    Lq = cfg.qformer.num_query
+    qt = sd["query_tokens"].float().expand(BT, -1, -1)
+    mask = torch.cat([torch.ones((BT, Lq), dtype=atts.dtype), atts], dim=1)  # :424
+    h = qformer_forward(sd, cfg, qt, ids, mask, encoder_hidden_states=torch.cat([ref.float(), target_embeds.float()], dim=1))
+    vl = F.linear(h[:, :Lq, :], sd["itm_head.weight"].float(), sd["itm_head.bias"].float())      # :440-441
+    return torch.softmax(vl.mean(dim=1), dim=-1)[:, -1]                      # :442-445
+
+
 # --------------------------------------------------------------------------------------
 # R7: ranking + metrics (integer work, numpy)
 # --------------------------------------------------------------------------------------
@@ -324,10 +345,17 @@ def fiq_metrics(sim: np.ndarray, tgt_idx: np.ndarray) -> Tuple[float, float]:
 
 
 def cirr_test_dicts(sim: np.ndarray, ref_idx: np.ndarray, group_idx: np.ndarray, pair_ids: Sequence[int],
-                    names: Sequence[str]):
-    """`generate_cirr_test_dicts` cirr_test_submission.py:81-130 without the rerank branch."""
+                    names: Sequence[str], rerank_scores: Optional[np.ndarray] = None):
+    """`generate_cirr_test_dicts` cirr_test_submission.py:81-130.  rerank_scores [nq, top] (optional): the stage-2
+    probabilities of the first `top` entries of every row, in stage-1 order; those entries are re-sorted by
+    (fl32(1 - score), stage-1 position) before the reference image is removed (:88-112)."""
     order = rank_stable(sim)
     nq, N = order.shape
+    if rerank_scores is not None:
+        top = rerank_scores.shape[1]
+        perm = np.argsort(distances(rerank_scores), axis=1, kind="stable")
+        order = order.copy()
+        order[:, :top] = np.take_along_axis(order[:, :top], perm, axis=1)
     order = order[order != ref_idx[:, None]].reshape(nq, N - 1)               # :116-120
     gmask = (order[..., None] == group_idx[:, None, :]).sum(-1).astype(bool)  # :122-124
     gorder = order[gmask].reshape(nq, -1)

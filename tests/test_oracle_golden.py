@@ -127,3 +127,52 @@ def test_caption_processing_matches_reference(golden_dir):
     for c1, c2, composed, processed in c["fiq"]:
         assert O.fiq_caption(c1, c2) == composed
         assert O.pre_caption(composed) == processed
+
+
+def test_planted_structure_case_matches_reference(golden_dir):
+    """Planted-structure weights (synth.plant_structure): scores spread over > 1.0, targets at planned ranks.  The oracle
+    reproduces the reference's scores, its stable order wherever the reference's own neighbouring scores differ by more
+    than 1e-5, and the numbers the reference's metric code printed for them."""
+    g = np.load(golden_dir / "planted_eva.npz", allow_pickle=False)
+    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
+    seed, n_img = int(g["seed"]), int(g["n_img"])
+    sd = synth.make_state_dict(cfg, seed=seed, planted=True)
+    images = synth.make_images(n_img, seed=seed, planted=True)
+    np.testing.assert_array_equal(images[:4, :, 0, :4].numpy(), g["image_probe"])
+    ids, mask, ref = (torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "ref_index"))
+    with torch.no_grad():
+        feats, raw = O.extract_target_features(sd, cfg, images)
+        fusion = O.fuse_queries(sd, cfg, raw[ref], ids, mask)
+        sim = O.similarity(fusion, feats).numpy()
+    np.testing.assert_allclose(feats[:4].numpy(), g["feats_head"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(fusion.numpy(), g["fusion"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(sim, g["sim"], atol=TOL, rtol=0)
+    spread = np.sort(g["sim"], axis=1)
+    assert np.mean(spread[:, -1] - spread[:, 0]) > 0.3                      # the point of planting structure
+    ref_i, tgt, grp = g["ref_index"], g["tgt_index"], g["groups"]
+    assert O.cirr_metrics(g["sim"], ref_i, tgt, grp) == pytest.approx(tuple(g["cirr"]), abs=1e-4)
+    assert O.fiq_metrics(g["sim"], tgt) == pytest.approx(tuple(g["fiq"]), abs=1e-4)
+    assert O.cirr_metrics(sim, ref_i, tgt, grp) == pytest.approx(tuple(g["cirr"]), abs=1e-4)   # on the oracle's own scores too
+    dicts = json.loads(str(g["test_dicts"]))
+    names = [f"img-{i:05d}" for i in range(n_img)]
+    top, sub = O.cirr_test_dicts(g["sim"], ref_i, grp, [1000 + i for i in range(len(ref_i))], names)
+    assert top == dicts["top"] and sub == dicts["sub"]
+
+
+def test_rerank_matches_reference(golden_dir):
+    """N2: the oracle's inference_rerank against the reference's Blip2QformerCirRerank.inference_rerank (514-token
+    cross-attention + itm_head + softmax), batched (3 queries x 4 candidates) and the single-query branch."""
+    g = np.load(golden_dir / "rerank_eva.npz", allow_pickle=False)
+    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]))
+    np.testing.assert_array_equal(images[:, :, 0, :4].numpy(), g["image_probe"])
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    ref, cand = torch.from_numpy(g["ref_index"]), torch.from_numpy(g["cand_index"])
+    with torch.no_grad():
+        raw = O.encode_image_tokens(sd, cfg, images)
+        prob = O.inference_rerank(sd, cfg, raw[ref], raw[cand.reshape(-1)], ids, mask)
+        one = O.inference_rerank(sd, cfg, raw[ref[:1]], raw[cand[0]], ids[:1], mask[:1])
+    np.testing.assert_allclose(prob.numpy(), g["prob"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(one.numpy(), g["prob_one"], atol=TOL, rtol=0)
+    assert np.all((g["prob"] > 0) & (g["prob"] < 1)) and np.ptp(g["prob"]) > 0.02
