@@ -128,6 +128,15 @@ typedef struct {
     void* out;     int64_t ldo;
     const float* key_mask;
     float scale;
+    /* Optional second key/value segment: the key axis is cat(segment 1: Tk tokens of (k, v) at batch row kv_index[b],
+     * segment 2: Tk2 tokens of (k2, v2) at batch row kv2_index[b]); index arrays are device int32 [B], NULL = b.
+     * This is the stage-2 rerank's cross-attention over cat(reference, candidate) image tokens
+     * (blip2_qformer_cir_rerank.py:430-437) without materialising the concatenation per (query, candidate) pair.
+     * Not combinable with key_mask. */
+    const void* k2; int64_t ldk2;
+    const void* v2; int64_t ldv2;
+    int32_t Tk2;
+    const int32_t* kv_index; const int32_t* kv2_index;
 } sprc_attention_args;
 int sprc_attention(const sprc_attention_args* a, sprc_stream s);
 
@@ -243,6 +252,36 @@ int sprc_qformer_image(const sprc_qformer_model* m, const float* raw, int32_t B,
 int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
                       const int64_t* input_ids, const int64_t* attention_mask, int32_t B,
                       float* fusion, void* fusion16, void* ws, size_t ws_bytes, sprc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage-2 rerank: Blip2QformerCirRerank.inference_rerank,
+ * lavis/models/blip2_models/blip2_qformer_cir_rerank.py:399-445; caller cirr_test_submission.py:88-112.
+ * The reference runs the Q-Former once per (query, candidate) pair over cat(reference, candidate) image tokens and
+ * projects those 514 tokens to K|V inside every pair.  K|V projections are per token, so they are computed ONCE per
+ * image (sprc_qformer_encode_kv) and a pair only names its two rows (index_a / index_b): 13 of the 19 GFLOP of a
+ * pair disappear.
+ * ---------------------------------------------------------------------------------------- */
+
+/* kv[B*tokens, n_cross*2*hidden] (compute dtype) = K|V projections of image tokens raw[B,tokens,enc_width] (fp32) for
+ * every cross-attention layer (Qformer.py:191-193).  Workspace: the bf16 copy of raw (bf16 engine only). */
+size_t sprc_qformer_kv_workspace_bytes(const sprc_qformer_model* m, int32_t B, int32_t tokens);
+int sprc_qformer_encode_kv(const sprc_qformer_model* m, const float* raw, int32_t B, int32_t tokens, void* kv,
+                           void* ws, size_t ws_bytes, sprc_stream s);
+
+/* prob[p] = softmax(mean over the 32 query rows of itm_head(Qformer(query_tokens, text_p, enc = cat(A[index_a[p]],
+ * B[index_b[p]]))))[1] for P (query, candidate) pairs.  kv_a [*, tokens_a, n_cross*2*hidden] / kv_b likewise come from
+ * sprc_qformer_encode_kv; index_a / index_b: device int32 [P] (NULL = p); input_ids / attention_mask [P, max_txt] int64
+ * (the query's caption repeated for each of its candidates); itm_w [2, hidden], itm_b [2] fp32. */
+size_t sprc_qformer_itm_workspace_bytes(const sprc_qformer_model* m, int32_t P);
+int sprc_qformer_itm(const sprc_qformer_model* m, const float* itm_w, const float* itm_b,
+                     const void* kv_a, int32_t tokens_a, const int32_t* index_a,
+                     const void* kv_b, int32_t tokens_b, const int32_t* index_b,
+                     const int64_t* input_ids, const int64_t* attention_mask, int32_t P,
+                     float* prob, void* ws, size_t ws_bytes, sprc_stream s);
+
+/* building block: prob[p] = softmax(W . mean_j h[p, j, :] + b)[1], j < Lq; h fp32 with `sample_stride` elements between samples */
+int sprc_itm_head(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* w, const float* b, int32_t P,
+                  float* prob, sprc_stream s);
 
 #ifdef __cplusplus
 }

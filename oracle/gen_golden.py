@@ -129,6 +129,12 @@ def metrics_goldens(out: Path):
             rows = [int(c[1:]) for c in captions]
             return self.sim[rows]
 
+        def inference_rerank(self, reference_feats, target_feats, captions):
+            # stage-2 double: P(match) of (query, gallery image) from a fixed table; the "raw embeddings" carry the image index
+            rows = torch.tensor([int(c[1:]) for c in captions])
+            cand = target_feats.view(len(rows), -1).long()
+            return self.rerank_table[rows[:, None], cand].reshape(-1)
+
     class CirrVal(Dataset):
         def __init__(self, names, ref, tgt, groups):
             self.names, self.ref, self.tgt, self.groups = names, ref, tgt, groups
@@ -162,7 +168,12 @@ def metrics_goldens(out: Path):
         fiq_txt = {"eval": lambda c: "q" + c.split(" ")[0][1:]}
         fiq = vb.compute_fiq_val_metrics(FiqVal(names, ref, tgt, groups), fm, feats, names, fiq_txt)
         top, sub = cts.generate_cirr_test_dicts(CirrTest(names, ref, tgt, groups), fm, feats, names, txt, False)
-        cases[name] = dict(nq=nq, N=N, seed=seed, ties=ties,
+        # the reference's --rerank branch (cirr_test_submission.py:88-112) with the stage-2 scores of the table above
+        table = np.random.default_rng(seed + 50).uniform(0.05, 0.95, size=(nq, N)).astype(np.float32)
+        fm.rerank_table = torch.from_numpy(table)
+        feats_rr = (torch.zeros(N, 1), torch.arange(N, dtype=torch.float32).unsqueeze(1))
+        top_rr, sub_rr = cts.generate_cirr_test_dicts(CirrTest(names, ref, tgt, groups), fm, feats_rr, names, txt, True)
+        cases[name] = dict(nq=nq, N=N, seed=seed, ties=ties, rerank_table=table.tolist(), rerank_top50=top_rr, rerank_subset3=sub_rr,
                            sim=sim.tolist(), ref=ref.tolist(), tgt=tgt.tolist(), groups=groups.tolist(),
                            cirr=list(cirr), fiq=list(fiq), test_top50=top, test_subset3=sub)
         print(name, "cirr", [round(x, 3) for x in cirr], "fiq", fiq)

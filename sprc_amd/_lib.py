@@ -38,7 +38,8 @@ class LayerNormArgs(C.Structure):
 class AttentionArgs(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("head_dim", i32), ("dtype", i32),
                 ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64), ("out", vp), ("ldo", i64),
-                ("key_mask", vp), ("scale", f32)]
+                ("key_mask", vp), ("scale", f32),
+                ("k2", vp), ("ldk2", i64), ("v2", vp), ("ldv2", i64), ("Tk2", i32), ("kv_index", vp), ("kv2_index", vp)]
 
 
 class QformerEmbedArgs(C.Structure):
@@ -111,6 +112,11 @@ SIGNATURES = {
     "sprc_vit_forward": (i32, [C.POINTER(VitModel), vp, i32, vp, vp, sz, vp]),
     "sprc_qformer_image": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, vp, sz, vp]),
     "sprc_qformer_fuse": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, i32, vp, vp, vp, sz, vp]),
+    "sprc_qformer_kv_workspace_bytes": (sz, [C.POINTER(QformerModel), i32, i32]),
+    "sprc_qformer_encode_kv": (i32, [C.POINTER(QformerModel), vp, i32, i32, vp, vp, sz, vp]),
+    "sprc_qformer_itm_workspace_bytes": (sz, [C.POINTER(QformerModel), i32]),
+    "sprc_qformer_itm": (i32, [C.POINTER(QformerModel), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, sz, vp]),
+    "sprc_itm_head": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, vp]),
 }
 
 _lib = None

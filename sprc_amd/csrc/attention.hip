@@ -13,11 +13,20 @@
 //   * head_dim 88 (EVA ViT-g) is zero-padded to 96 = 6 MFMA k-steps; Tk is padded to a multiple of
 //     32 with -inf scores.
 // f32 kernel: exact-fp32 VALU restatement for parity mode (one wave per query row).
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace sprc {
 
 constexpr float LOG2E = 1.4426950408889634f;
+
+// sum of the two bf16 values packed in a dword, as floats.  The softmax denominator is accumulated from the ROUNDED
+// probabilities that enter the P.V MFMAs: numerator and denominator then carry the same rounding, and the error of the
+// weighted average scales with |v - mean(v)| instead of |v| (first order: sum_k p_k eps_k (v_k - vbar) / sum_k p_k).
+__device__ __forceinline__ float rounded_pair_sum(uint32_t pk) {
+    return __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
+}
 
 struct AttnParams {
     int B, H, Tq, Tk, dh;
@@ -27,7 +36,24 @@ struct AttnParams {
     char* out; int64_t ldo;
     const float* key_mask;
     float scale;
+    // optional second key/value segment (stage-2 rerank: keys = cat(reference tokens, candidate tokens)): keys [0, Tk1) come
+    // from (k, v) at batch row idx1[b] (b when null), keys [Tk1, Tk) from (k2, v2) at batch row idx2[b]; Tk1 == Tk: one segment
+    int Tk1;
+    const char* k2; int64_t ldk2;
+    const char* v2; int64_t ldv2;
+    const int32_t* idx1; const int32_t* idx2;
 };
+
+// byte address of head h of key/value token t of batch b (t in the concatenated key axis)
+__device__ __forceinline__ const char* kv_token(const AttnParams& p, const char* seg1, int64_t ld1, const char* seg2, int64_t ld2,
+                                                int b, int h, int t) {
+    if (t < p.Tk1) {
+        const int64_t row = (int64_t)(p.idx1 ? p.idx1[b] : b) * p.Tk1 + t;
+        return seg1 + (row * ld1 + (int64_t)h * p.dh) * 2;
+    }
+    const int64_t row = (int64_t)(p.idx2 ? p.idx2[b] : b) * (p.Tk - p.Tk1) + (t - p.Tk1);
+    return seg2 + (row * ld2 + (int64_t)h * p.dh) * 2;
+}
 
 // ------------------------------------------------------------------------------------------------
 template <int DHP, int NW>
@@ -38,7 +64,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     constexpr int KROW = DHP * 2 + 16;        // bytes per K row in LDS
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
-    const int bh = blockIdx.x, b = bh / p.H, h = bh % p.H;
+    int b, h;                                 // all heads of an image on one XCD (block i runs on XCD i % 8): see attn_stream_kernel
+    if ((p.B & 7) == 0) { const int x = blockIdx.x & 7, i = blockIdx.x >> 3; h = i % p.H; b = (i / p.H) * 8 + x; }
+    else { b = blockIdx.x / p.H; h = blockIdx.x % p.H; }
     const int Tkp = (p.Tk + 31) & ~31;
     const int VROW = Tkp * 2 + 8;             // bytes per V^T row in LDS
     char* sK = smem;
@@ -46,8 +74,6 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     float* sM = reinterpret_cast<float*>(sV + (size_t)DHP * VROW);
 
     const int dh = p.dh;
-    const char* kbase = p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2;
-    const char* vbase = p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2;
 
     // ---- stage K (row-major, zero padded) and V transposed (VT[d][key], two keys per 32-bit write).  Global loads are
     // issued in batches of UNR independent requests per thread before any LDS write, so a batch costs one memory
@@ -60,7 +86,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
         for (int u = 0; u < UNR; ++u) {
             const int it = it0 + u * NTH, t = it / CPR, c = it % CPR;
             val[u] = u32x4{0u, 0u, 0u, 0u};
-            if (it < nK && t < p.Tk && c * 8 < dh) val[u] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)t * p.ldk * 2 + c * 16);
+            if (it < nK && t < p.Tk && c * 8 < dh) val[u] = *reinterpret_cast<const u32x4*>(kv_token(p, p.k, p.ldk, p.k2, p.ldk2, b, h, t) + c * 16);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -76,8 +102,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
             const int it = it0 + u * NTH, kp = it % (Tkp / 2), c = it / (Tkp / 2), t0 = kp * 2;
             va[u] = vb[u] = u32x4{0u, 0u, 0u, 0u};
             if (it < nV && c * 8 < dh) {
-                if (t0 < p.Tk) va[u] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t0 * p.ldv * 2 + c * 16);
-                if (t0 + 1 < p.Tk) vb[u] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(t0 + 1) * p.ldv * 2 + c * 16);
+                if (t0 < p.Tk) va[u] = *reinterpret_cast<const u32x4*>(kv_token(p, p.v, p.ldv, p.v2, p.ldv2, b, h, t0) + c * 16);
+                if (t0 + 1 < p.Tk) vb[u] = *reinterpret_cast<const u32x4*>(kv_token(p, p.v, p.ldv, p.v2, p.ldv2, b, h, t0 + 1) + c * 16);
             }
         }
 #pragma unroll
@@ -168,7 +194,6 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
                 }
             }
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run = l_run * alpha + psum;
             m_run = m_new;
             if (__any(alpha != 1.0f)) {          // the running max moved for some query of this wave (rare after the first tiles)
 #pragma unroll
@@ -178,13 +203,18 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
             }
             // P^T fragments (B operand): k-slot j uses this lane's regs 8j..8j+7
             bf16x8 pf[2];
+            psum = 0.f;                          // re-summed from the rounded probabilities (see rounded_pair_sum)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 u32x4 pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);   // v_cvt_pk_bf16_f32
+                for (int e = 0; e < 4; ++e) {
+                    pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);   // v_cvt_pk_bf16_f32
+                    psum += rounded_pair_sum(pk[e]);
+                }
                 pf[j] = __builtin_bit_cast(bf16x8, pk);
             }
+            l_run = l_run * alpha + psum;
             // O^T += V^T . P^T ; A operand lane (d = r32, half): keys {16j+4half+0..3, 16j+8+4half+0..3}
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -230,8 +260,16 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
 // back to back on ONE XCD (block b runs on XCD b % 8) and the re-reads hit that XCD's L2.
 // Same math as above: S^T = K.Q^T (a lane owns one query column), online softmax in the exp2 domain, O^T = V^T.P^T with P
 // kept in registers; V is transposed on its way into LDS (two keys per 32-bit write).
-template <int DHP>
-__global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int nqb, int xcd_map) {
+// VALU diet (PMC on the first version: 20 VALU instructions per MFMA, the waves 50 % in s_waitcnt): (1) the padded-key mask
+// only exists in the code of the LAST tile; (2) with head_dim 88 in a 96-row V^T tile, row 88 holds ones, so the softmax
+// denominator falls out of the P.V MFMAs (no 16 adds per tile, and it is rescaled with O); (3) the running max only moves
+// when a tile's max exceeds it by more than 2^RESCALE_LOG2 (guide T13): P then stays <= 256 -- exact in fp32 accumulation,
+// same relative precision in bf16 -- and the 48-multiply rescale of O runs in the first tile and rarely after;
+// (4) global addresses of a thread's pieces advance by a constant per tile.
+constexpr float RESCALE_LOG2 = 8.0f;
+
+template <int DHP, bool ONES>
+__global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int nqb, int xcd_map, int debug) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 192, KS = DHP / 16, DT = DHP / 32, CPR = DHP / 8;
     constexpr int KROW = DHP * 2 + 16;        // bytes per K row in LDS (conflict-free ds_read_b128 across 32 rows)
@@ -241,52 +279,83 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
     static_assert(16 * CPR <= NT, "one (key pair, chunk) item of V per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
-    int bh, qb;
-    if (xcd_map) { const int x = blockIdx.x & 7, i = blockIdx.x >> 3; qb = i % nqb; bh = (i / nqb) * 8 + x; }
-    else { bh = blockIdx.x / nqb; qb = blockIdx.x % nqb; }
-    const int b = bh / p.H, h = bh % p.H, dh = p.dh;
+    // Block b runs on XCD b % 8.  A token row of the packed qkv tensor holds the K (V) slices of ALL heads back to back
+    // (176 B each for ViT-g: not a multiple of the 128-B line), so neighbouring heads share cache lines: all heads and
+    // query blocks of one image are placed on ONE XCD, consecutively, and every fetched line is used by that XCD's L2
+    // (heads spread over the XCDs fetched 457 MB per launch against 300 MB of distinct bytes).
+    int b, h, qb;
+    if (xcd_map == 2) { const int x = blockIdx.x & 7, i = blockIdx.x >> 3; qb = i % nqb; h = (i / nqb) % p.H; b = (i / (nqb * p.H)) * 8 + x; }
+    else if (xcd_map == 1) { const int x = blockIdx.x & 7, i = blockIdx.x >> 3; qb = i % nqb; const int bh = (i / nqb) * 8 + x; b = bh / p.H; h = bh % p.H; }
+    else { const int bh = blockIdx.x / nqb; qb = blockIdx.x % nqb; b = bh / p.H; h = bh % p.H; }
+    const int dh = p.dh;
     const int nkt = (p.Tk + 31) >> 5;
-    const char* kbase = p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2;
-    const char* vbase = p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2;
+    const bool ragged = (p.Tk & 31) != 0;
 
     // ---- this thread's share of a tile: KPT 16-B pieces of K, one (key pair, 8-wide chunk) item of V ----
-    int k_row[KPT], k_c[KPT];
+    const char* kptr[KPT];
+    bool k_on[KPT];
+    int k_row[KPT], k_lds[KPT];
 #pragma unroll
-    for (int u = 0; u < KPT; ++u) { const int idx = tid + u * NT; k_row[u] = idx / CPR; k_c[u] = idx % CPR; }
-    const int v_kp = tid & 15, v_c = tid >> 4;
-    const bool v_item = v_c < CPR;
-    u32x4 kreg[KPT], va, vb;
-    auto fetch = [&](int kt) {
+    for (int u = 0; u < KPT; ++u) {
+        const int idx = tid + u * NT, c = idx % CPR;
+        k_row[u] = idx / CPR;
+        k_on[u] = k_row[u] < 32 && c * 8 < dh;                   // columns >= head_dim stay zero (pad of the 96-wide tile)
+        k_lds[u] = k_row[u] * KROW + c * 16;
+        kptr[u] = p.k + (((int64_t)b * p.Tk + min(k_row[u], 31)) * p.ldk + (int64_t)h * dh) * 2 + c * 16;
+    }
+    // consecutive lanes take consecutive 16-B chunks of ONE row (like K): with lanes running over the key pairs instead, a
+    // wave instruction touched 16 different rows (16-32 cache lines for 1 KB)
+    const int v_kp = tid / CPR, v_c = tid % CPR;
+    const bool v_item = v_kp < 16, v_on = v_item && v_c * 8 < dh;
+    const bool v_ones = ONES && v_item && v_c * 8 == dh;         // this thread owns V^T rows dh .. dh+7: row dh = ones
+    const char* vptr = p.v + (((int64_t)b * p.Tk + v_kp * 2) * p.ldv + (int64_t)h * dh) * 2 + v_c * 16;
+    const int64_t kstep = 32 * p.ldk * 2, vstep = 32 * p.ldv * 2, vnext = p.ldv * 2;
+    // Two staging register sets: the loads of tile t+2 are issued while tile t is computed and tile t+1 waits in the other
+    // set (ablation: with one set -- loads issued one tile ahead -- the kernel ran 175 us, 108 us with the loop's loads
+    // removed, 148 us with the MATH removed: a chain of nine exposed ~2-us memory round trips per workgroup).
+    struct Stage { u32x4 kreg[KPT], va, vb; };
+    Stage stg[2];
+    auto fetch = [&](Stage& g, int kt, auto tail_) {             // tail: the tile may hold keys >= Tk
+        constexpr bool TAIL = decltype(tail_)::value;
 #pragma unroll
         for (int u = 0; u < KPT; ++u) {
-            const int t = kt * 32 + k_row[u];
-            kreg[u] = u32x4{0u, 0u, 0u, 0u};
-            if (k_row[u] < 32 && t < p.Tk && k_c[u] * 8 < dh)
-                kreg[u] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)t * p.ldk * 2 + k_c[u] * 16);
+            g.kreg[u] = u32x4{0u, 0u, 0u, 0u};
+            if (k_on[u] && (!TAIL || kt * 32 + k_row[u] < p.Tk)) g.kreg[u] = *reinterpret_cast<const u32x4*>(kptr[u]);
+            kptr[u] += kstep;
         }
-        va = vb = u32x4{0u, 0u, 0u, 0u};
-        const int t0 = kt * 32 + v_kp * 2;
-        if (v_item && v_c * 8 < dh) {
-            if (t0 < p.Tk) va = *reinterpret_cast<const u32x4*>(vbase + (int64_t)t0 * p.ldv * 2 + v_c * 16);
-            if (t0 + 1 < p.Tk) vb = *reinterpret_cast<const u32x4*>(vbase + (int64_t)(t0 + 1) * p.ldv * 2 + v_c * 16);
+        g.va = g.vb = u32x4{0u, 0u, 0u, 0u};
+        if (v_on) {
+            const int t0 = kt * 32 + v_kp * 2;
+            if (!TAIL || t0 < p.Tk) g.va = *reinterpret_cast<const u32x4*>(vptr);
+            if (!TAIL || t0 + 1 < p.Tk) g.vb = *reinterpret_cast<const u32x4*>(vptr + vnext);
         }
+        vptr += vstep;
     };
-    auto commit = [&](int buf) {
+    auto fetch_any = [&](Stage& g, int kt) {                     // tile kt if it exists (the last one may be ragged)
+        if (kt >= nkt) return;
+        if (ragged && kt + 1 == nkt) fetch(g, kt, std::true_type{}); else fetch(g, kt, std::false_type{});
+    };
+    auto commit = [&](Stage& g, int buf) {
+        u32x4 va = g.va, vb = g.vb;
         char* sK = smem + buf * BUF;
         char* sV = sK + KBYTES;
 #pragma unroll
         for (int u = 0; u < KPT; ++u)
-            if (k_row[u] < 32) *reinterpret_cast<u32x4*>(sK + k_row[u] * KROW + k_c[u] * 16) = kreg[u];
+            if (k_row[u] < 32) *reinterpret_cast<u32x4*>(sK + k_lds[u]) = g.kreg[u];
         if (v_item) {
+            if (v_ones) va[0] = vb[0] = 0x3f80u;                 // bf16 1.0 in row dh for both keys of the pair
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t lo = (va[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                const uint32_t hi = (vb[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e) * VROW + v_kp * 4) = lo | (hi << 16);
+            for (int e = 0; e < 8; e += 2) {                     // rows (e, e+1) of the chunk: low / high halves of dword e/2
+                const uint32_t a = va[e >> 1], c = vb[e >> 1];
+                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e) * VROW + v_kp * 4) = (a & 0xffffu) | (c << 16);
+                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e + 1) * VROW + v_kp * 4) = (a >> 16) | (c & 0xffff0000u);
             }
         }
     };
-    fetch(0);
+    using std::false_type;
+    using std::true_type;
+    fetch_any(stg[0], 0);
+    fetch_any(stg[1], 1);
 
     // Q^T fragments (B operand): lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8]
     const int qt = qb * 3 + wave;
@@ -297,7 +366,7 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
     for (int ks = 0; ks < KS; ++ks) {
         const int d0 = ks * 16 + half * 8;
         u32x4 val = {0u, 0u, 0u, 0u};
-        if (d0 < dh) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
+        if (d0 < dh && !(debug & 32)) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
         qf[ks] = __builtin_bit_cast(bf16x8, val);
     }
     f32x16 o[DT];
@@ -307,13 +376,10 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float sc = p.scale * LOG2E;
-    const bool ragged = (p.Tk & 31) != 0;
 
-    commit(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) fetch(kt + 1);
+    // one 32-key tile out of buffer kt & 1
+    auto tile = [&](int kt, auto tail_) {
+        constexpr bool TAIL = decltype(tail_)::value;
         const char* sK = smem + (kt & 1) * BUF;
         const char* sV = sK + KBYTES;
         f32x16 s;
@@ -325,7 +391,7 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 32);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         }
-        if (ragged && !more) {                  // padded keys of the last tile: key of reg r = kt*32 + (r&3) + 8*(r>>2) + 4*half
+        if constexpr (TAIL) {                   // padded keys: key of reg r = kt*32 + (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= p.Tk) s[r] = -INFINITY;
@@ -333,31 +399,32 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
         float mx = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx * sc);      // every tile holds >= 1 real key: m_new is finite
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_new));
-            psum += s[r];
-        }
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (__any(alpha != 1.0f)) {
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;            // every tile holds >= 1 real key: finite
+        if (__any(mx - m_run > RESCALE_LOG2)) {                  // always in the first tile (m_run = -inf), rarely afterwards
+            const float m_new = (mx - m_run > RESCALE_LOG2) ? mx : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 1 for the queries that keep their max
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run));
         bf16x8 pf[2];
+        float psum = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             u32x4 pk;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
+            for (int e = 0; e < 4; ++e) {
+                pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
+                if constexpr (!ONES) psum += rounded_pair_sum(pk[e]);       // the denominator sums what the MFMA multiplies
+            }
             pf[j] = __builtin_bit_cast(bf16x8, pk);
         }
+        if constexpr (!ONES) l_run += psum;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const char* vrow = sV + (dt * 32 + r32) * VROW + (4 * half) * 2;
@@ -369,32 +436,69 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j], o[dt], 0, 0, 0);
             }
         }
-        if (more) commit((kt + 1) & 1);         // that buffer was last read in tile kt-1: every wave is past its barrier
-        __syncthreads();
+    };
+
+    commit(stg[0], 0);
+    __syncthreads();
+    const int n_main = ragged ? nkt - 1 : nkt;                   // tiles without padded keys
+    // iteration kt: tile kt is in LDS buffer kt & 1, tile kt+1 in flight / landed in register set (kt+1) & 1; set kt & 1 is
+    // free (committed at the end of iteration kt-1) and takes the loads of tile kt+2.  Unrolled by two: static set indices.
+    auto step = [&](int kt, auto par_) {
+        constexpr int PAR = decltype(par_)::value;
+        if (!(debug & 1)) fetch_any(stg[PAR], kt + 2);
+        if (!(debug & 4)) tile(kt, false_type{});
+        if (kt + 1 < nkt && !(debug & 2)) commit(stg[PAR ^ 1], (kt + 1) & 1);   // buffer last read in tile kt-1: every wave is past its barrier
+        if (!(debug & 8)) __syncthreads();
+    };
+    for (int kt = 0; kt < n_main; kt += 2) {
+        step(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < n_main) step(kt + 1, std::integral_constant<int, 1>{});
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (ragged) tile(nkt - 1, true_type{});
+    float l_tot;
+    if constexpr (ONES) {
+        // row dh = 88 of O^T (tile dt = 2, d_local = 24 -> reg 12 of the half-0 lanes) is sum_k P[q][k] . 1
+        static_assert(DHP == 96, "ones row: head_dim 88 in a 96-row tile");
+        l_tot = __shfl(o[2][12], r32, 64);
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
     const float inv = 1.0f / l_tot;
-    const int qo = qt * 32 + r32;
-    if (qo < p.Tq) {
-        char* optr = p.out + (((int64_t)b * p.Tq + qo) * p.ldo + (int64_t)h * dh) * 2;
+    // Output through LDS: in registers a lane owns one query ROW, so storing straight out is 12 x 8 B per lane with every
+    // wave instruction touching 32 different rows -- store-issue bound, 22 us of the launch (ablation).  Each wave
+    // transposes its 32 x head_dim tile through a private strip of the (now idle) K/V buffers and writes whole rows as
+    // 16-B pieces: 5.5 instructions per lane, 176 contiguous bytes per row.
+    constexpr int ORS = DHP * 2 + 16;         // strip row stride: 16-B aligned, 2-way bank conflicts at most
+    static_assert(3 * 32 * ORS <= 2 * BUF, "output strips fit in the K/V buffers");
+    __syncthreads();                          // every wave is done reading K/V tiles
+    char* so = smem + wave * (32 * ORS);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = dt * 32 + 8 * g + 4 * half;
-                if (d0 < dh) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
-                    pk.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
-                    *reinterpret_cast<uint2*>(optr + d0 * 2) = pk;
-                }
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = dt * 32 + 8 * g + 4 * half;
+            if (d0 < dh) {
+                uint2 pk;
+                pk.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+                pk.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(so + r32 * ORS + d0 * 2) = pk;
             }
+        }
+    __builtin_amdgcn_wave_barrier();          // the strip is private to this wave: LDS operations of one wave complete in order
+    const int cpr = dh >> 3;
+    char* obase = p.out + (((int64_t)b * p.Tq + qt * 32) * p.ldo + (int64_t)h * dh) * 2;
+    if (!(debug & 16)) {
+        for (int idx = lane; idx < 32 * cpr; idx += 64) {
+            const int row = idx / cpr, c = idx - row * cpr;
+            if (qt * 32 + row < p.Tq)
+                *reinterpret_cast<u32x4*>(obase + (int64_t)row * p.ldo * 2 + c * 16) = *reinterpret_cast<const u32x4*>(so + row * ORS + c * 16);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // exact fp32: one wave per query row; lanes = keys for QK^T, lanes = head dims for PV.
-constexpr int F32_MAXK = 8;     // keys per lane -> Tk <= 512
+constexpr int F32_MAXK = 9;     // keys per lane -> Tk <= 576 (the rerank's 514 = 2 x 257 encoder tokens)
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -405,8 +509,11 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
     float* qs = reinterpret_cast<float*>(smem) + wave * (dh + p.Tk);
     float* ps = qs + dh;
     const float* q = reinterpret_cast<const float*>(p.q) + ((int64_t)b * p.Tq + qi) * p.ldq + (int64_t)h * dh;
-    const float* kb = reinterpret_cast<const float*>(p.k) + (int64_t)b * p.Tk * p.ldk + (int64_t)h * dh;
-    const float* vb = reinterpret_cast<const float*>(p.v) + (int64_t)b * p.Tk * p.ldv + (int64_t)h * dh;
+    // fp32 rows of the (possibly two-segment) key axis
+    auto kv_row = [&](const char* seg1, int64_t ld1, const char* seg2, int64_t ld2, int t) -> const float* {
+        if (t < p.Tk1) return reinterpret_cast<const float*>(seg1) + ((int64_t)(p.idx1 ? p.idx1[b] : b) * p.Tk1 + t) * ld1 + (int64_t)h * dh;
+        return reinterpret_cast<const float*>(seg2) + ((int64_t)(p.idx2 ? p.idx2[b] : b) * (p.Tk - p.Tk1) + (t - p.Tk1)) * ld2 + (int64_t)h * dh;
+    };
     for (int d = lane; d < dh; d += 64) qs[d] = q[d];
     __syncthreads();
     float s[F32_MAXK];
@@ -416,7 +523,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
         const int key = lane + i * 64;
         s[i] = -INFINITY;
         if (key < p.Tk) {
-            const float* kr = kb + (int64_t)key * p.ldk;
+            const float* kr = kv_row(p.k, p.ldk, p.k2, p.ldk2, key);
             float acc = 0.f;
             for (int d = 0; d < dh; d += 4) {
                 const float4 kv = *reinterpret_cast<const float4*>(kr + d);
@@ -444,7 +551,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
     float* o = reinterpret_cast<float*>(p.out) + ((int64_t)b * p.Tq + qi) * p.ldo + (int64_t)h * dh;
     for (int d = lane; d < dh; d += 64) {
         float acc = 0.f;
-        for (int key = 0; key < p.Tk; ++key) acc = fmaf(ps[key], vb[(int64_t)key * p.ldv + d], acc);
+        for (int key = 0; key < p.Tk; ++key) acc = fmaf(ps[key], kv_row(p.v, p.ldv, p.v2, p.ldv2, key)[d], acc);
         if (valid) o[d] = acc * inv;
     }
 }
@@ -468,12 +575,16 @@ static int launch_bf16(const AttnParams& p, hipStream_t st) {
     return SPRC_OK;
 }
 
-template <int DHP>
+template <int DHP, bool ONES>
 static int launch_stream(const AttnParams& p, hipStream_t st) {
     constexpr int BUF = 32 * (DHP * 2 + 16) + DHP * 72;
     const int nqb = ((p.Tq + 31) / 32 + 2) / 3;
     const int bh = p.B * p.H;
-    hipLaunchKernelGGL(attn_stream_kernel<DHP>, dim3(bh * nqb), dim3(192), 2 * BUF, st, p, nqb, (bh % 8) == 0 ? 1 : 0);
+    // SPRC_ATTN_DEBUG (timing ablations, WRONG results): 1 no global loads in the loop, 2 no LDS commit, 4 no tile math, 8 no barrier
+    static const int debug = [] { const char* e = getenv("SPRC_ATTN_DEBUG"); return e ? atoi(e) : 0; }();
+    static const int xcd = [] { const char* e = getenv("SPRC_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    const int xmap = !xcd ? 0 : (xcd == 3 && (bh % 8) == 0) ? 1 : (p.B % 8) == 0 ? 2 : (bh % 8) == 0 ? 1 : 0;
+    hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES>), dim3(bh * nqb), dim3(192), 2 * BUF, st, p, nqb, xmap, debug);
     SPRC_CHECK_LAUNCH("sprc_attention(bf16, streaming)");
     return SPRC_OK;
 }
@@ -484,25 +595,33 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
     using namespace sprc;
     SPRC_REQUIRE(a && a->q && a->k && a->v && a->out, "sprc_attention: null pointer");
     SPRC_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0 && a->head_dim > 0, "sprc_attention: bad shape");
-    AttnParams p{a->B, a->H, a->Tq, a->Tk, a->head_dim, (const char*)a->q, a->ldq, (const char*)a->k, a->ldk,
-                 (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale};
+    const bool two = a->k2 != nullptr;
+    SPRC_REQUIRE(!two || (a->v2 && a->Tk2 > 0 && !a->key_mask), "sprc_attention: a second key segment needs k2, v2, Tk2 > 0 and no key mask");
+    SPRC_REQUIRE(two || (!a->kv_index && !a->kv2_index && !a->v2), "sprc_attention: kv_index / kv2_index / v2 come with a second key segment (k2)");
+    const int Tk_all = a->Tk + (two ? a->Tk2 : 0);
+    AttnParams p{a->B, a->H, a->Tq, Tk_all, a->head_dim, (const char*)a->q, a->ldq, (const char*)a->k, a->ldk,
+                 (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale,
+                 a->Tk, (const char*)a->k2, a->ldk2, (const char*)a->v2, a->ldv2, a->kv_index, a->kv2_index};
     hipStream_t st = (hipStream_t)s;
     const double bh = (double)a->B * a->H, esz = a->dtype == SPRC_BF16 ? 2.0 : 4.0;
-    ProfScope prof(SPRC_K_ATTN, st, 4.0 * bh * a->Tq * (double)a->Tk * a->head_dim,
-                   bh * a->head_dim * esz * (2.0 * a->Tq + 2.0 * a->Tk));
+    ProfScope prof(SPRC_K_ATTN, st, 4.0 * bh * a->Tq * (double)Tk_all * a->head_dim,
+                   bh * a->head_dim * esz * (2.0 * a->Tq + 2.0 * Tk_all));
     if (a->dtype == SPRC_BF16) {
         SPRC_REQUIRE(a->head_dim % 8 == 0 && a->head_dim <= 96, "sprc_attention(bf16): head_dim=%d unsupported", a->head_dim);
         SPRC_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0,
                      "sprc_attention(bf16): leading dims must be multiples of 8");
         SPRC_REQUIRE(((uintptr_t)a->q % 16) == 0 && ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0 &&
                          ((uintptr_t)a->out % 8) == 0, "sprc_attention(bf16): misaligned pointer");
+        SPRC_REQUIRE(!two || (a->ldk2 % 8 == 0 && a->ldv2 % 8 == 0 && ((uintptr_t)a->k2 % 16) == 0 && ((uintptr_t)a->v2 % 16) == 0),
+                     "sprc_attention(bf16): second key segment misaligned");
         const bool small = a->Tq <= 128;
         // long query axes without a key mask (the ViT blocks): streaming kernel, five small workgroups per CU
         // (SPRC_ATTN_STREAM=0 keeps the resident-K/V kernel for A/B runs)
         static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
-        if (stream && !small && a->key_mask == nullptr) {
-            if (a->head_dim <= 64) return launch_stream<64>(p, st);
-            return launch_stream<96>(p, st);
+        if (stream && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
+            if (a->head_dim <= 64) return launch_stream<64, false>(p, st);
+            if (a->head_dim == 88) return launch_stream<96, true>(p, st);      // denominator from the ones row of the padded V^T tile
+            return launch_stream<96, false>(p, st);
         }
         // 257 tokens = 9 query tiles: nine waves (one tile each, the K / V staging shared by nine) beat eight waves of which
         // one carries two tiles: 209 -> 195 us per ViT-g layer (SPRC_ATTN_NINE=0 for the A/B)
@@ -516,9 +635,9 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
         return small ? launch_bf16<96, 4>(p, st) : launch_bf16<96, 8>(p, st);
     }
     SPRC_REQUIRE(a->dtype == SPRC_F32, "sprc_attention: bad dtype %d", a->dtype);
-    SPRC_REQUIRE(a->Tk <= 64 * F32_MAXK, "sprc_attention(f32): Tk=%d > %d", a->Tk, 64 * F32_MAXK);
-    SPRC_REQUIRE(a->head_dim % 4 == 0 && a->ldk % 4 == 0, "sprc_attention(f32): head_dim/ldk must be multiples of 4");
-    const size_t lds = 4 * (size_t)(a->head_dim + a->Tk) * sizeof(float);
+    SPRC_REQUIRE(Tk_all <= 64 * F32_MAXK, "sprc_attention(f32): Tk=%d > %d", Tk_all, 64 * F32_MAXK);
+    SPRC_REQUIRE(a->head_dim % 4 == 0 && a->ldk % 4 == 0 && (!two || a->ldk2 % 4 == 0), "sprc_attention(f32): head_dim/ldk must be multiples of 4");
+    const size_t lds = 4 * (size_t)(a->head_dim + Tk_all) * sizeof(float);
     hipLaunchKernelGGL(attn_f32_kernel, dim3((a->Tq + 3) / 4, a->H, a->B), dim3(256), lds, st, p);
     SPRC_CHECK_LAUNCH("sprc_attention(f32)");
     return SPRC_OK;

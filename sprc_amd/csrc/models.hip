@@ -68,13 +68,30 @@ static int lnorm(hipStream_t st, int dt, int M, int D, const float* x, const flo
     return sprc_layernorm(&a, st);
 }
 
+// where the cross-attention K|V rows of a batch come from: one [B, Ta, ld] buffer (image pass, fusion), or per-sample rows
+// of two buffers through index arrays (stage-2 rerank: cat(reference, candidate) tokens)
+struct KvSrc {
+    const void* a; int Ta; const int32_t* ia;
+    const void* b; int Tb; const int32_t* ib;       // b == nullptr: one segment
+    int64_t ld;                                      // elements per token row: n_cross * 2 * hidden
+};
+
 static int attn(hipStream_t st, int dt, int B, int H, int Tq, int Tk, int dh, const void* q, int64_t ldq, const void* k,
-                int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, const float* mask, float scale) {
+                int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, const float* mask, float scale,
+                const KvSrc* two = nullptr, size_t seg2_off = 0) {
     sprc_attention_args a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.head_dim = dh; a.dtype = dt;
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
     a.key_mask = mask; a.scale = scale;
+    if (two != nullptr) {                            // k / v already point at segment 1; segment 2 at the same byte offsets
+        a.kv_index = two->ia;
+        if (two->b != nullptr) {
+            a.k2 = (const char*)two->b + seg2_off; a.ldk2 = two->ld;
+            a.v2 = (const char*)a.k2 + (size_t)((const char*)v - (const char*)k); a.ldv2 = two->ld;
+            a.Tk2 = two->Tb; a.kv2_index = two->ib;
+        }
+    }
     return sprc_attention(&a, st);
 }
 
@@ -117,12 +134,12 @@ struct QfBufs {
     float *h32, *a32, *g32, *t32, *proj, *mask;
 };
 
-static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& b, QfBufs& q) {
+static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& b, QfBufs& q, bool with_kv = true) {
     const size_t es = dtype_size(m->dtype);
     const size_t S = (size_t)m->num_query + m->max_txt, R = (size_t)B * S, Hd = m->hidden;
     const size_t E = (size_t)B * enc_tokens;
-    q.enc = (m->dtype == SPRC_BF16) ? b.take(E * m->enc_width * es) : nullptr;
-    q.kv = b.take(E * (size_t)m->n_cross * 2 * Hd * es);
+    q.enc = (with_kv && m->dtype == SPRC_BF16) ? b.take(E * m->enc_width * es) : nullptr;
+    q.kv = with_kv ? b.take(E * (size_t)m->n_cross * 2 * Hd * es) : nullptr;
     q.h32 = (float*)b.take(R * Hd * 4); q.h16 = b.take(R * Hd * es);
     q.a32 = (float*)b.take(R * Hd * 4); q.a16 = b.take(R * Hd * es);
     q.g32 = (float*)b.take(R * Hd * 4); q.g16 = b.take(R * Hd * es);
@@ -138,13 +155,13 @@ static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& 
 
 // one Q-Former encoder stack over x32/x16 [B, S, hidden]; cross-attention + query FFN on rows [:Lq] when
 // `kv` is given (Qformer.py:434-468), text FFN on rows [Lq:]; text FFN on all rows otherwise (:469-475).
-static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int B, int S, int enc_tokens, bool with_enc,
+static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int B, int S, const KvSrc* kvs,
                     const float* mask, float* x32, void* x16) {
+    const bool with_enc = kvs != nullptr;
     const int dt = m->dtype, Hd = m->hidden, H = m->heads, dh = m->head_dim, F = m->ffn, Lq = m->num_query;
     const int R = B * S;
     const float sc = 1.0f / sqrtf((float)dh);                                   // Qformer.py:250
     const size_t es = dtype_size(dt);
-    const int64_t ldkv = (int64_t)m->n_cross * 2 * Hd;
     const sprc_rowmap qmap = {Lq, S, 0}, tmap = {S - Lq, S, Lq};
     const bool split = with_enc && S > Lq;         // rows [:Lq] and [Lq:] take different paths
     // SPRC_FUSE_ADD=1: the post-LN residual adds (Qformer.py:294,380) ride on the LayerNorm kernels (sprc_layernorm add16),
@@ -168,8 +185,11 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
             const int Rq = B * Lq;
             if (L.has_cross) {
                 RUN(gemm(st, dt, dt, Rq, Hd, Hd, q.a16, Hd, L.cq, q.cq, Hd, SPRC_ACT_NONE, nullptr, 0, rq));
-                const char* kp = (const char*)q.kv + (size_t)L.cross_index * 2 * Hd * es;
-                RUN(attn(st, dt, B, H, Lq, enc_tokens, dh, q.cq, Hd, kp, ldkv, kp + Hd * es, ldkv, q.ctx, Hd, nullptr, sc));
+                const size_t off = (size_t)L.cross_index * 2 * Hd * es;          // this layer's K|V block inside a token row
+                const char* kp = (const char*)kvs->a + off;
+                const bool plain = kvs->b == nullptr && kvs->ia == nullptr;
+                RUN(attn(st, dt, B, H, Lq, kvs->Ta, dh, q.cq, Hd, kp, kvs->ld, kp + Hd * es, kvs->ld, q.ctx, Hd, nullptr, sc,
+                         plain ? nullptr : kvs, off));
                 if (fuse_add) {
                     RUN(gemm(st, dt, SPRC_F16, Rq, Hd, Hd, q.ctx, Hd, L.cross_out, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, ID_MAP, rq));
                     RUN(lnorm(st, dt, Rq, Hd, q.a32, L.cross_ln_w, L.cross_ln_b, m->ln_eps, q.a32, q.a16, rq, q.a16));
@@ -232,15 +252,16 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
 }
 
 // K|V projections of the image tokens for every cross-attention layer in ONE GEMM (Qformer.py:191-193)
-static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, const float* enc32, int B, int enc_tokens) {
+static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, void* enc16, void* kv_out, const float* enc32, int B,
+                        int enc_tokens) {
     const int E = B * enc_tokens;
     const void* enc = enc32;
     if (m->dtype == SPRC_BF16) {
-        RUN(sprc_cast_f32_to_bf16(enc32, (uint16_t*)q.enc, (size_t)E * m->enc_width, st));
-        enc = q.enc;
+        RUN(sprc_cast_f32_to_bf16(enc32, (uint16_t*)enc16, (size_t)E * m->enc_width, st));
+        enc = enc16;
     }
     const int Nkv = m->n_cross * 2 * m->hidden;
-    return gemm(st, m->dtype, m->dtype, E, Nkv, m->enc_width, enc, m->enc_width, m->ckv_all, q.kv, Nkv);
+    return gemm(st, m->dtype, m->dtype, E, Nkv, m->enc_width, enc, m->enc_width, m->ckv_all, kv_out, Nkv);
 }
 
 static int check_qf(const sprc_qformer_model* m) {
@@ -387,7 +408,8 @@ extern "C" int sprc_qformer_image(const sprc_qformer_model* m, const float* raw,
     }
     hipStream_t st = (hipStream_t)s;
     const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query;
-    RUN(qf_encode_kv(m, st, q, raw, B, T));
+    RUN(qf_encode_kv(m, st, q.enc, q.kv, raw, B, T));
+    const KvSrc kvs{q.kv, T, nullptr, nullptr, 0, nullptr, (int64_t)m->n_cross * 2 * Hd};
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
     e.B = B; e.Lq = Lq; e.Lt = 0; e.hidden = Hd; e.out_dtype = dt;
@@ -395,7 +417,7 @@ extern "C" int sprc_qformer_image(const sprc_qformer_model* m, const float* raw,
     e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, Lq, T, true, nullptr, q.h32, q.h16));
+    RUN(qf_stack(m, st, q, B, Lq, &kvs, nullptr, q.h32, q.h16));
     RUN(gemm(st, dt, SPRC_F32, B * Lq, m->embed_dim, Hd, q.h16, Hd, m->vision_proj, q.proj, m->embed_dim));
     return sprc_l2norm_rows(q.proj, m->embed_dim, feats, feats16, m->embed_dim, B * Lq, m->embed_dim, dt, st);
 }
@@ -405,7 +427,7 @@ extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_e
                                  void* fusion16, void* ws, size_t ws_bytes, sprc_stream s) {
     RUN(check_qf(m));
     SPRC_REQUIRE(ref_embeds && input_ids && attention_mask && fusion && ws && B > 0, "sprc_qformer_fuse: bad arguments");
-    SPRC_REQUIRE(enc_tokens == 257, "sprc_qformer_fuse: enc_tokens=%d (workspace is planned for 257)", enc_tokens);
+    SPRC_REQUIRE(enc_tokens == 257, "sprc_qformer_fuse: enc_tokens=%d (sprc_qformer_workspace_bytes plans for 257)", enc_tokens);
     SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_qformer_fuse: workspace must be 256-byte aligned");
     Bump b(ws, ws_bytes);
     QfBufs q;
@@ -416,7 +438,8 @@ extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_e
     }
     hipStream_t st = (hipStream_t)s;
     const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query, Lt = m->max_txt, S = Lq + Lt;
-    RUN(qf_encode_kv(m, st, q, ref_embeds, B, enc_tokens));
+    RUN(qf_encode_kv(m, st, q.enc, q.kv, ref_embeds, B, enc_tokens));
+    const KvSrc kvs{q.kv, enc_tokens, nullptr, nullptr, 0, nullptr, (int64_t)m->n_cross * 2 * Hd};
     RUN(sprc_qformer_mask(attention_mask, q.mask, B, Lq, Lt, st));
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
@@ -427,14 +450,70 @@ extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_e
     e.query_embeds = m->query_tokens; e.q_bstride = 0;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, enc_tokens, true, q.mask, q.h32, q.h16));
+    RUN(qf_stack(m, st, q, B, S, &kvs, q.mask, q.h32, q.h16));
     // pass 2: pass-1 query rows as query_embeds (re-LayerNormed by the embedding LN), no image (:341-346)
     e.query_embeds = q.h32; e.q_bstride = (int64_t)S * Hd;
     e.y32 = q.g32; e.y16 = q.g16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, enc_tokens, false, q.mask, q.g32, q.g16));
+    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.g32, q.g16));
     // fusion = normalize(text_proj(pass2[:, 32, :]))  (:348-350): row Lq of every sample
     const sprc_rowmap cls_row = {1, S, Lq};
     RUN(gemm(st, dt, SPRC_F32, B, m->embed_dim, Hd, q.g16, Hd, m->text_proj, q.proj, m->embed_dim, SPRC_ACT_NONE, nullptr, 0, cls_row));
     return sprc_l2norm_rows(q.proj, m->embed_dim, fusion, fusion16, m->embed_dim, B, m->embed_dim, dt, st);
+}
+
+// ---- stage-2 rerank: blip2_qformer_cir_rerank.py:399-445 ------------------------------------------
+extern "C" size_t sprc_qformer_kv_workspace_bytes(const sprc_qformer_model* m, int32_t B, int32_t tokens) {
+    if (!m || B <= 0 || tokens <= 0) return 0;
+    return (m->dtype == SPRC_BF16 ? (size_t)B * tokens * m->enc_width * 2 : 0) + 512;
+}
+
+extern "C" int sprc_qformer_encode_kv(const sprc_qformer_model* m, const float* raw, int32_t B, int32_t tokens, void* kv,
+                                      void* ws, size_t ws_bytes, sprc_stream s) {
+    RUN(check_qf(m));
+    SPRC_REQUIRE(raw && kv && B > 0 && tokens > 0, "sprc_qformer_encode_kv: bad arguments");
+    SPRC_REQUIRE(m->dtype != SPRC_BF16 || (ws && ((uintptr_t)ws % 256) == 0 && ws_bytes >= sprc_qformer_kv_workspace_bytes(m, B, tokens) - 512),
+                 "sprc_qformer_encode_kv: workspace too small or misaligned");
+    SPRC_REQUIRE(((uintptr_t)kv % 16) == 0, "sprc_qformer_encode_kv: kv must be 16-byte aligned");
+    return qf_encode_kv(m, (hipStream_t)s, ws, kv, raw, B, tokens);
+}
+
+extern "C" size_t sprc_qformer_itm_workspace_bytes(const sprc_qformer_model* m, int32_t P) {
+    if (!m || P <= 0) return 0;
+    Bump b(nullptr, 0);
+    QfBufs q;
+    return qf_plan(m, P, 0, b, q, false) + 256;
+}
+
+extern "C" int sprc_qformer_itm(const sprc_qformer_model* m, const float* itm_w, const float* itm_b, const void* kv_a,
+                                int32_t tokens_a, const int32_t* index_a, const void* kv_b, int32_t tokens_b,
+                                const int32_t* index_b, const int64_t* input_ids, const int64_t* attention_mask, int32_t P,
+                                float* prob, void* ws, size_t ws_bytes, sprc_stream s) {
+    RUN(check_qf(m));
+    SPRC_REQUIRE(itm_w && itm_b && kv_a && kv_b && input_ids && attention_mask && prob && ws && P > 0, "sprc_qformer_itm: bad arguments");
+    SPRC_REQUIRE(tokens_a > 0 && tokens_b > 0, "sprc_qformer_itm: empty key segment");
+    SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_qformer_itm: workspace must be 256-byte aligned");
+    Bump b(ws, ws_bytes);
+    QfBufs q;
+    qf_plan(m, P, 0, b, q, false);
+    if (!b.ok) {
+        set_error("sprc_qformer_itm: workspace too small (%zu bytes given)", ws_bytes);
+        return SPRC_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query, Lt = m->max_txt, S = Lq + Lt;
+    RUN(sprc_qformer_mask(attention_mask, q.mask, P, Lq, Lt, st));
+    sprc_qformer_embed_args e;
+    memset(&e, 0, sizeof(e));
+    e.B = P; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt; e.vocab = m->vocab;
+    e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
+    e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
+    e.query_embeds = m->query_tokens; e.q_bstride = 0;
+    e.y32 = q.h32; e.y16 = q.h16;
+    RUN(sprc_qformer_embed(&e, st));
+    // one Q-Former pass in call shape (ii) over cat(reference, candidate) tokens (:430-437)
+    const KvSrc kvs{kv_a, tokens_a, index_a, kv_b, tokens_b, index_b, (int64_t)m->n_cross * 2 * Hd};
+    RUN(qf_stack(m, st, q, P, S, &kvs, q.mask, q.h32, q.h16));
+    // itm_head on the query rows, mean over them, softmax, P(match)  (:439-445)
+    return sprc_itm_head(q.h32, (int64_t)S * Hd, Lq, Hd, itm_w, itm_b, P, prob, st);
 }

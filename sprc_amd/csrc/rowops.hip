@@ -258,6 +258,49 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
     return SPRC_OK;
 }
 
+// prob[p] = softmax(mean_j (W h[p,j,:] + b))[1] over the first Lq rows of every sample (blip2_qformer_cir_rerank.py:439-445);
+// mean_j (W h_j + b) = W (mean_j h_j) + b.  One wave per sample.
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void itm_head_kernel(const float* __restrict__ h, int64_t sample_stride, int Lq,
+                                                                       int D, const float* __restrict__ w,
+                                                                       const float* __restrict__ bias, int P, float* prob) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int nch = D >> 2;
+    RowRegs acc, r;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Lq; ++j) {
+        load_row(r, h + (int64_t)p * sample_stride + (int64_t)j * D, nch, lane);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { acc.v[c].x += r.v[c].x; acc.v[c].y += r.v[c].y; acc.v[c].z += r.v[c].z; acc.v[c].w += r.v[c].w; }
+    }
+    float l[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        load_row(r, w + (int64_t)k * D, nch, lane);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) d += (acc.v[c].x * r.v[c].x + acc.v[c].y * r.v[c].y) + (acc.v[c].z * r.v[c].z + acc.v[c].w * r.v[c].w);
+        l[k] = wave_sum(d) / (float)Lq + bias[k];
+    }
+    if (lane == 0) {
+        const float mx = fmaxf(l[0], l[1]);
+        const float e0 = expf(l[0] - mx), e1 = expf(l[1] - mx);
+        prob[p] = e1 / (e0 + e1);
+    }
+}
+
+extern "C" int sprc_itm_head(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* w, const float* b, int32_t P,
+                             float* prob, sprc_stream s) {
+    SPRC_REQUIRE(h && w && b && prob && P > 0 && Lq > 0, "sprc_itm_head: bad arguments");
+    SPRC_REQUIRE(D % 4 == 0 && D <= 64 * 4 * MAXC && sample_stride % 4 == 0, "sprc_itm_head: D=%d unsupported", D);
+    const dim3 grid((P + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(itm_head_kernel, grid, block, 0, (hipStream_t)s, h, sample_stride, Lq, D, w, b, P, prob);
+    SPRC_CHECK_LAUNCH("sprc_itm_head");
+    return SPRC_OK;
+}
+
 extern "C" int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream s) {
     SPRC_REQUIRE(a && a->query_embeds && a->gamma && a->beta, "sprc_qformer_embed: null pointer");
     SPRC_REQUIRE(a->B > 0 && a->Lq > 0 && a->Lt >= 0, "sprc_qformer_embed: bad shape");

@@ -101,7 +101,10 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype: int, want32=T
     return y32, y16
 
 
-def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=None, out=None):
+def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=None, out=None,
+              k2=None, v2=None, Tk2=0, ld2=0, kv_index=None, kv2_index=None):
+    """k2 / v2 (optional): a second key segment of Tk2 tokens appended to the key axis; kv_index / kv2_index: int32 [B] batch
+    rows of the two segments (see sprc_attention_args)."""
     lib = L.load()
     dt = L.SPRC_BF16 if q.dtype == torch.bfloat16 else L.SPRC_F32
     if out is None:
@@ -111,6 +114,9 @@ def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=No
     a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv
     a.out, a.ldo = out.data_ptr(), out.stride(0)
     a.key_mask, a.scale = _ptr(key_mask), scale
+    if k2 is not None:
+        a.k2, a.ldk2, a.v2, a.ldv2, a.Tk2 = k2.data_ptr(), ld2, v2.data_ptr(), ld2, Tk2
+    a.kv_index, a.kv2_index = _ptr(kv_index), _ptr(kv2_index)
     L.check(lib.sprc_attention(C.byref(a), _stream()), "sprc_attention")
     return out
 
@@ -278,6 +284,9 @@ class Engine:
         m.ckv_all = self._lin(torch.cat([w.to(self.device) for w in ckv_w]), torch.cat([b_.to(self.device) for b_ in ckv_b]))
         m.vision_proj = self._lin(sd["vision_proj.weight"], sd["vision_proj.bias"])
         m.text_proj = self._lin(sd["text_proj.weight"], sd["text_proj.bias"])
+        # image-text-matching head of the stage-2 rerank (blip2_qformer_cir_rerank.py:88): fp32, two rows
+        self.itm_w = self._f32(sd["itm_head.weight"]) if "itm_head.weight" in sd else None
+        self.itm_b = self._f32(sd["itm_head.bias"]) if "itm_head.bias" in sd else None
         m.layers = C.cast(layers, C.POINTER(L.QfLayer))
         self._qf_layers, self.qf = layers, m
 
@@ -310,6 +319,8 @@ class Engine:
     def qformer_image(self, raw: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """feats[B,32,E] fp32 (unit rows) + compute-dtype copy (bf16 mode)."""
         raw = raw.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(raw.shape[1:]) != (self.cfg.vit.tokens, self.cfg.vit.width):        # the C call plans for exactly this shape
+            raise ValueError(f"raw embeddings must be [B, {self.cfg.vit.tokens}, {self.cfg.vit.width}], got {tuple(raw.shape)}")
         B, E, Lq = raw.shape[0], self.cfg.embed_dim, self.cfg.qformer.num_query
         feats = torch.empty((B, Lq, E), dtype=torch.float32, device=self.device)
         f16 = torch.empty((B, Lq, E), dtype=self.tdt, device=self.device) if self.dt == L.SPRC_BF16 else None
@@ -324,6 +335,8 @@ class Engine:
     def qformer_fuse(self, ref_embeds: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor):
         """fusion[B,E] fp32 (unit rows) + compute-dtype copy (bf16 mode)."""
         ref = ref_embeds.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(ref.shape[1:]) != (self.cfg.vit.tokens, self.cfg.vit.width):
+            raise ValueError(f"reference embeddings must be [B, {self.cfg.vit.tokens}, {self.cfg.vit.width}], got {tuple(ref.shape)}")
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
         B, E = ref.shape[0], self.cfg.embed_dim
@@ -341,3 +354,57 @@ class Engine:
                                                None if f16 is None else f16[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
                                                _stream()), "sprc_qformer_fuse")
         return fusion, f16
+
+    # ---- stage-2 rerank ------------------------------------------------------------------
+    @property
+    def kv_width(self) -> int:
+        return self.qf.n_cross * 2 * self.cfg.qformer.hidden
+
+    def encode_kv(self, raw: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """kv[B, tokens, n_cross*2*hidden] (compute dtype): cross-attention K|V projections of image tokens, once per image."""
+        raw = raw.to(device=self.device, dtype=torch.float32).contiguous()
+        B, T, D = raw.shape
+        if D != self.cfg.vit.width:
+            raise ValueError(f"raw embeddings must be [B, tokens, {self.cfg.vit.width}]")
+        kv = out if out is not None else torch.empty((B, T, self.kv_width), dtype=self.tdt, device=self.device)
+        step = max(1, min(self.max_batch, 256))
+        for s in range(0, B, step):
+            n = min(step, B - s)
+            need = int(self.lib.sprc_qformer_kv_workspace_bytes(C.byref(self.qf), n, T))
+            ws = self._ws.get("kv")
+            if ws is None or ws.numel() < need:
+                ws = self._ws["kv"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            L.check(self.lib.sprc_qformer_encode_kv(C.byref(self.qf), raw[s:s + n].data_ptr(), n, T, kv[s:s + n].data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), _stream()), "sprc_qformer_encode_kv")
+        return kv
+
+    def itm(self, kv_a: torch.Tensor, index_a: torch.Tensor, kv_b: torch.Tensor, index_b: torch.Tensor,
+            input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """prob[P] = P(match) of P (query, candidate) pairs: pair p attends over cat(kv_a[index_a[p]], kv_b[index_b[p]])."""
+        if self.itm_w is None:
+            raise L.SprcError("the state dict has no itm_head.*: stage-2 rerank needs the rerank checkpoint's ITM head")
+        ia = index_a.to(device=self.device, dtype=torch.int32).contiguous()
+        ib = index_b.to(device=self.device, dtype=torch.int32).contiguous()
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        P = ia.shape[0]
+        if ib.shape[0] != P or ids.shape != (P, self.cfg.max_txt_len) or mask.shape != ids.shape:
+            raise ValueError("index_a / index_b / input_ids / attention_mask must describe the same P pairs")
+        for kv in (kv_a, kv_b):
+            if kv.dtype != self.tdt or kv.dim() != 3 or kv.shape[2] != self.kv_width or not kv.is_contiguous():
+                raise ValueError("kv_a / kv_b must come from Engine.encode_kv")
+        if P and (int(ia.max()) >= kv_a.shape[0] or int(ib.max()) >= kv_b.shape[0] or int(ia.min()) < 0 or int(ib.min()) < 0):
+            raise IndexError("pair index out of range")
+        prob = torch.empty((P,), dtype=torch.float32, device=self.device)
+        for s in range(0, P, self.max_batch):
+            n = min(self.max_batch, P - s)
+            need = int(self.lib.sprc_qformer_itm_workspace_bytes(C.byref(self.qf), n))
+            ws = self._ws.get("itm")
+            if ws is None or ws.numel() < need:
+                ws = self._ws["itm"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            L.check(self.lib.sprc_qformer_itm(C.byref(self.qf), self.itm_w.data_ptr(), self.itm_b.data_ptr(),
+                                              kv_a.data_ptr(), kv_a.shape[1], ia[s:s + n].data_ptr(),
+                                              kv_b.data_ptr(), kv_b.shape[1], ib[s:s + n].data_ptr(),
+                                              ids[s:s + n].data_ptr(), mask[s:s + n].data_ptr(), n, prob[s:s + n].data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream()), "sprc_qformer_itm")
+        return prob

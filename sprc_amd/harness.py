@@ -229,8 +229,15 @@ def generate_cirr_test_predictions(blip_model, relative_test_dataset, index_name
     return torch.vstack(sims), reference_names, group_members, pairs_id, captions_all, name_to_feat
 
 
-def cirr_test_dicts_from_sim(sim: torch.Tensor, ref_idx, group_idx, pairs_id, index_names: Sequence[str]):
-    """top-50 names (reference removed) and top-3 subset names per pair id, from top-51 + 6 exact ranks."""
+RERANK_TOP = 50          # cirr_test_submission.py:91-92 (`step = 50; top = 50`)
+
+
+def cirr_test_dicts_from_sim(sim: torch.Tensor, ref_idx, group_idx, pairs_id, index_names: Sequence[str], rerank_fn=None):
+    """top-50 names (reference removed) and top-3 subset names per pair id, from top-51 + 6 exact ranks.
+
+    rerank_fn(query_rows[list], cand_idx[len, 50] int64) -> P(match)[len, 50]: the stage-2 branch
+    (cirr_test_submission.py:88-112): the first 50 entries of every row are re-sorted by (fl32(1 - P), stage-1 position)
+    BEFORE the reference image is removed; entries beyond 50 keep their stage-1 order."""
     ref_idx, group_idx = np.asarray(ref_idx, dtype=np.int64), np.asarray(group_idx, dtype=np.int64)
     names = np.asarray(index_names)
     N = sim.shape[1]
@@ -238,6 +245,22 @@ def cirr_test_dicts_from_sim(sim: torch.Tensor, ref_idx, group_idx, pairs_id, in
     _, idx = E.topk(sim.contiguous(), k)
     idx = idx.cpu().numpy()
     g_rank = E.rank_of(sim.contiguous(), torch.from_numpy(group_idx)).cpu().numpy().astype(np.int64)
+    if rerank_fn is not None:
+        top = min(RERANK_TOP, N)
+        pos = np.broadcast_to(np.arange(N, dtype=np.int64), (len(pairs_id), N)).copy()     # placeholder ranks for non-top entries
+        for s in range(0, len(pairs_id), 50):
+            rows = list(range(s, min(s + 50, len(pairs_id))))
+            cand = idx[rows, :top].astype(np.int64)
+            prob = rerank_fn(rows, torch.from_numpy(cand)).detach().float().cpu().numpy()
+            perm = np.argsort((np.float32(1.0) - prob.astype(np.float32)), axis=1, kind="stable")
+            idx[rows, :top] = np.take_along_axis(cand, perm, axis=1)
+        # subset order after reranking: a member inside the top-50 takes its new position, others keep their stage-1 rank
+        for q in range(len(pairs_id)):
+            where = {int(g): p for p, g in enumerate(idx[q, :top])}
+            for j in range(group_idx.shape[1]):
+                g = int(group_idx[q, j])
+                if g in where:
+                    g_rank[q, j] = where[g]
     top, sub = {}, {}
     for q, pid in enumerate(pairs_id):
         row = [i for i in idx[q] if i >= 0 and i != ref_idx[q]][: min(50, N - 1)]       # cirr_test_submission.py:116-120,127
@@ -252,13 +275,25 @@ def cirr_test_dicts_from_sim(sim: torch.Tensor, ref_idx, group_idx, pairs_id, in
 def generate_cirr_test_dicts(relative_test_dataset, blip_model, index_features, index_names: List[str], txt_processors,
                              rerank=False):
     """-> (pairid -> top-50 names, pairid -> top-3 subset names)   (cirr_test_submission.py:61-132)"""
-    if rerank:
-        raise NotImplementedError("stage-2 rerank needs `inference_rerank`, which blip2_cir_align_prompt does not define "
-                                  "(cirr_test_submission.py:88-112; SURVEY.md section 8(f) N2)")
-    sim, reference_names, group_members, pairs_id, _, _ = generate_cirr_test_predictions(
+    sim, reference_names, group_members, pairs_id, captions, name_to_feat = generate_cirr_test_predictions(
         blip_model, relative_test_dataset, index_names, index_features, txt_processors)
     print("Compute CIRR prediction dicts")
     n2i = {n: i for i, n in enumerate(index_names)}
     ref = [n2i[n] for n in reference_names]
     grp = [[n2i.get(n, -1) for n in g] for g in group_members]
-    return cirr_test_dicts_from_sim(sim, ref, grp, pairs_id, index_names)
+    rerank_fn = None
+    if rerank:                              # cirr_test_submission.py:88-112
+        print("reranking now")
+        if hasattr(blip_model, "rerank_pairs"):
+            # K|V projections once per gallery image (the reference recomputes them inside every (query, candidate) pair)
+            kv = blip_model.engine().encode_kv(torch.stack([name_to_feat[n] for n in index_names]).float())
+
+            def rerank_fn(rows, cand):
+                r = torch.tensor([ref[q] for q in rows])
+                return blip_model.rerank_pairs(kv, r, kv, cand, [captions[q] for q in rows])
+        else:                               # any model that follows the reference protocol
+            def rerank_fn(rows, cand):
+                refs = _stack_refs(name_to_feat, [reference_names[q] for q in rows]).to(blip_model.device)
+                tg = torch.stack([name_to_feat[index_names[int(i)]] for i in cand.reshape(-1)]).to(blip_model.device)
+                return blip_model.inference_rerank(refs, tg, [captions[q] for q in rows]).view(len(rows), -1)
+    return cirr_test_dicts_from_sim(sim, ref, grp, pairs_id, index_names, rerank_fn=rerank_fn)

@@ -158,13 +158,51 @@ class Blip2QformerCirAlignPrompt(nn.Module):
                              return_tensors="pt").to(self.device)
         return self.inference_ids(reference_embeds, target_feats, tok.input_ids, tok.attention_mask)
 
+    @torch.no_grad()
+    def inference_rerank(self, reference_embeds: torch.Tensor, target_embeds: torch.Tensor, text: List[str]) -> torch.Tensor:
+        """Stage-2 rerank, `Blip2QformerCirRerank.inference_rerank` (blip2_qformer_cir_rerank.py:399-445):
+        reference_embeds [B,257,D], target_embeds [B*T,257,D] (T candidates per query, query-major), text: B captions
+        -> P(match) [B*T].  K|V projections of the image tokens are computed once per image instead of once per pair."""
+        if isinstance(text, str):
+            text = [text]
+        B, BT = reference_embeds.shape[0], target_embeds.shape[0]
+        if len(text) != B or BT % B:
+            raise ValueError("one caption per reference image and T candidates per query are required")
+        T = BT // B
+        tok = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_txt_len,
+                             return_tensors="pt").to(self.device)
+        eng = self.engine()
+        kv_ref, kv_tgt = eng.encode_kv(reference_embeds), eng.encode_kv(target_embeds)
+        ia = torch.arange(B, device=self.device).repeat_interleave(T)
+        ib = torch.arange(BT, device=self.device)
+        return eng.itm(kv_ref, ia, kv_tgt, ib, tok.input_ids.repeat_interleave(T, dim=0), tok.attention_mask.repeat_interleave(T, dim=0))
+
+    @torch.no_grad()
+    def rerank_pairs(self, kv_ref: torch.Tensor, ref_index: torch.Tensor, kv_gallery: torch.Tensor, cand_index: torch.Tensor,
+                     text: List[str]) -> torch.Tensor:
+        """The cached form the harness uses: kv_* from `engine().encode_kv`; query q = (kv_ref[ref_index[q]], text[q]) is
+        scored against gallery rows cand_index[q, :] -> P(match) [nq, T]."""
+        nq, T = cand_index.shape
+        tok = self.tokenizer(text, padding="max_length", truncation=True, max_length=self.max_txt_len,
+                             return_tensors="pt").to(self.device)
+        ia = ref_index.to(self.device).repeat_interleave(T)
+        prob = self.engine().itm(kv_ref, ia, kv_gallery, cand_index.reshape(-1), tok.input_ids.repeat_interleave(T, dim=0),
+                                 tok.attention_mask.repeat_interleave(T, dim=0))
+        return prob.view(nq, T)
+
     def forward(self, samples):
         raise NotImplementedError("training forward (align_prompt.py:95-200) is outside the retrieval hot path "
                                   "(SURVEY.md section 8(f) N4)")
 
 
 # ---- registry + loader (lavis/common/registry.py:83-110, lavis/models/__init__.py:204-249) -----------
-_MODEL_REGISTRY: Dict[str, type] = {"blip2_cir_align_prompt": Blip2QformerCirAlignPrompt}
+class Blip2QformerCirRerank(Blip2QformerCirAlignPrompt):
+    """Checkpoint-key / registry alias of the stage-2 model class (blip2_qformer_cir_rerank.py:26-27): same trunk and
+    Q-Former, `inference_rerank` + `itm_head`; its frozen Q-Former copy (Fformer) is training-only and not loaded."""
+
+
+_MODEL_REGISTRY: Dict[str, type] = {"blip2_cir_align_prompt": Blip2QformerCirAlignPrompt,
+                                    "blip2_cir_rerank": Blip2QformerCirRerank}
 
 
 def get_model_class(name: str):

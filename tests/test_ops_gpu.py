@@ -519,3 +519,26 @@ def test_profiler_start_pause_resume_and_busy_time():
     lib.sprc_prof_enable(1)                              # start afresh drops the old records
     lib.sprc_prof_enable(0)
     assert collect()["gemm_bf16"].launches == 0
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_attention_two_key_segments(dtype):
+    """Second key/value segment + per-sample row indices (the stage-2 rerank's cross-attention over cat(reference,
+    candidate) tokens): equals attention over the explicitly concatenated keys."""
+    B, H, Tq, T1, T2, dh, NA, NB = 5, 12, 32, 257, 257, 64, 3, 4
+    D = H * dh
+    q = _rand((B, Tq, D), 90)
+    ka, va = _rand((NA, T1, D), 91), _rand((NA, T1, D), 92)
+    kb, vb = _rand((NB, T2, D), 93), _rand((NB, T2, D), 94)
+    ia, ib = torch.tensor([2, 0, 1, 2, 0], dtype=torch.int32), torch.tensor([3, 3, 0, 1, 2], dtype=torch.int32)
+    if dtype == "bf16":
+        q, ka, va, kb, vb = (_bf(t) for t in (q, ka, va, kb, vb))
+    k = torch.cat([ka[ia.long()], kb[ib.long()]], dim=1).float()
+    v = torch.cat([va[ia.long()], vb[ib.long()]], dim=1).float()
+    ref = _attn_ref(q.float().view(B, Tq, H, dh).transpose(1, 2), k.view(B, T1 + T2, H, dh).transpose(1, 2),
+                    v.view(B, T1 + T2, H, dh).transpose(1, 2), dh ** -0.5).transpose(1, 2).reshape(B * Tq, D)
+    out = E.attention(q.to(DEV).view(B * Tq, D), ka.to(DEV).view(NA * T1, D), va.to(DEV).view(NA * T1, D), B, H, Tq, T1, dh, D, D, D,
+                      dh ** -0.5, k2=kb.to(DEV).view(NB * T2, D), v2=vb.to(DEV).view(NB * T2, D), Tk2=T2, ld2=D,
+                      kv_index=ia.to(DEV), kv2_index=ib.to(DEV)).cpu()
+    tol = 2e-2 if dtype == "bf16" else 2e-5
+    torch.testing.assert_close(out.float().double(), ref, atol=tol, rtol=tol)
