@@ -283,6 +283,18 @@ int sprc_qformer_itm(const sprc_qformer_model* m, const float* itm_w, const floa
 int sprc_itm_head(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* w, const float* b, int32_t P,
                   float* prob, sprc_stream s);
 
+/* ------------------------------------------------------------------------------------------
+ * Image preprocessing: the reference's targetpad_transform(target_ratio, dim)
+ * = TargetPad -> Resize(dim, BICUBIC) -> CenterCrop(dim) -> ToTensor -> Normalize, src/data_utils.py:49-72, :91-105.
+ * src: ONE decoded image on the device, uint8 RGB, HWC, `src_stride` bytes per row.  out: fp32 [3, dim, dim].
+ * Bit-exact with the reference transform (PIL's 8-bit two-pass bicubic resampler): tap tables are computed on the host
+ * in double, the kernels do the 22-bit fixed-point arithmetic.  mean / std: host pointers to 3 floats.
+ * ---------------------------------------------------------------------------------------- */
+size_t sprc_preprocess_workspace_bytes(int32_t src_h, int32_t src_w, float target_ratio, int32_t dim);
+int sprc_preprocess_targetpad(const uint8_t* src, int32_t src_h, int32_t src_w, int64_t src_stride, float target_ratio,
+                              int32_t dim, const float* mean, const float* std, float* out,
+                              void* ws, size_t ws_bytes, sprc_stream s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,8 @@ SIGNATURES = {
     "sprc_qformer_itm_workspace_bytes": (sz, [C.POINTER(QformerModel), i32]),
     "sprc_qformer_itm": (i32, [C.POINTER(QformerModel), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, sz, vp]),
     "sprc_itm_head": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, vp]),
+    "sprc_preprocess_workspace_bytes": (sz, [i32, i32, f32, i32]),
+    "sprc_preprocess_targetpad": (i32, [vp, i32, i32, i64, f32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, sz, vp]),
 }
 
 _lib = None

@@ -34,16 +34,16 @@ def model_fingerprint(model) -> str:
     for k, v in sorted(model.state_dict().items()):
         t = v.detach().to("cpu").contiguous()
         h.update(k.encode()); h.update(str(tuple(t.shape)).encode()); h.update(str(t.dtype).encode())
-        h.update(t.view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+        h.update(t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b"")
     return h.hexdigest()
 
 
-def _gallery(dataset, model, cache, tag, backbone, dtype):
+def _gallery(dataset, model, cache, tag, backbone, dtype, num_workers: int = 2):
     """Encoded gallery `((feats, raw), names)`: from the feature store `<cache>/<tag>-...-<checkpoint fingerprint>.safetensors`
     when it exists AND was written by this checkpoint, else encoded now (and stored when a cache directory was given).
     No reference counterpart: utils.py:46-77 re-encodes on every run."""
     if not cache:
-        return extract_index_blip_features(dataset, model)
+        return extract_index_blip_features(dataset, model, num_workers=num_workers)
     fp = model_fingerprint(model)
     path = os.path.join(cache, f"{tag}-{backbone}-{dtype}-{fp[:16]}.safetensors")
     if os.path.exists(path):
@@ -52,19 +52,29 @@ def _gallery(dataset, model, cache, tag, backbone, dtype):
             print(f"loaded {len(names)} gallery rows from {path} ({meta})")
             return (feats, raw), names
         print(f"{path}: written by another checkpoint ({meta.get('checkpoint_sha256', '?')[:16]}), re-encoding")
-    (feats, raw), names = extract_index_blip_features(dataset, model)
+    (feats, raw), names = extract_index_blip_features(dataset, model, num_workers=num_workers)
     save_index(path, feats, names, raw=raw, backbone=backbone, compute_dtype=dtype, checkpoint_sha256=fp)
     return (feats, raw), names
 
 
-def _load(blip_model_name, backbone, model_path, dtype):
+def _load(blip_model_name, backbone, model_path, dtype, vit_depth=None):
     device = _device()
+    kw = {}
+    if vit_depth is not None:                      # truncated backbone (smoke tests of the entry points; not a reference flag)
+        from .config import get_config
+        kw["cfg"] = get_config(backbone, vit_depth=vit_depth)
     model, _, txt = load_model_and_preprocess(name=blip_model_name, model_type=backbone, is_eval=False, device=device,
-                                              compute_dtype=dtype)
+                                              compute_dtype=dtype, **kw)
     ckpt = torch.load(model_path, map_location=device)
     msg = model.load_state_dict(ckpt[model.__class__.__name__], strict=False)     # blip_validate.py:107-109
     print("Missing keys {}".format(msg.missing_keys))
     return model, txt
+
+
+def _geometric_mean(values) -> float:
+    """statistics.geometric_mean raises when a recall is exactly 0 (the reference's script then dies after the whole
+    evaluation, blip_validate.py:131); report 0.0 instead."""
+    return geometric_mean(values) if all(v > 0 for v in values) else 0.0
 
 
 def _sharded() -> bool:
@@ -76,41 +86,50 @@ def _rank0() -> bool:
     return int(os.environ.get("RANK", "0")) == 0
 
 
-def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16", index_cache=None):
-    from .data_utils import CIRRDataset, targetpad_transform
-    model, txt = _load(blip_model_name, backbone, blip_model_path, dtype)
-    preprocess = targetpad_transform(1.25, 224)
+def _preprocess(gpu: bool, device):
+    """(transform, DataLoader workers): the reference's targetpad_transform(1.25, 224) on the host (PIL) or with the pixel
+    work on the GPU (bit-identical; the transform then runs in the main process)."""
+    from .data_utils import targetpad_transform, targetpad_transform_gpu
+    return (targetpad_transform_gpu(1.25, 224, device), 0) if gpu else (targetpad_transform(1.25, 224), 2)
+
+
+def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16", index_cache=None, gpu_preprocess=False,
+                       vit_depth=None):
+    from .data_utils import CIRRDataset
+    model, txt = _load(blip_model_name, backbone, blip_model_path, dtype, vit_depth)
+    preprocess, workers = _preprocess(gpu_preprocess, model.device)
     relative_val = CIRRDataset("val", "relative", preprocess)
     classic_val = CIRRDataset("val", "classic", preprocess)
     if _sharded():
         from .dist_eval import compute_cirr_val_metrics_sharded
-        r = compute_cirr_val_metrics_sharded(relative_val, classic_val, model, txt)
+        r = compute_cirr_val_metrics_sharded(relative_val, classic_val, model, txt, num_workers=workers)
     else:
-        feats, names = _gallery(classic_val, model, index_cache, "cirr-val", backbone, dtype)
+        feats, names = _gallery(classic_val, model, index_cache, "cirr-val", backbone, dtype, workers)
         r = compute_cirr_val_metrics(relative_val, model, feats, names, txt)
     g1, g2, g3, r1, r5, r10, r50 = r
     out = {"group_recall_at1": g1, "group_recall_at2": g2, "group_recall_at3": g3, "recall_at1": r1, "recall_at5": r5,
            "recall_at10": r10, "recall_at50": r50, "mean(R@5+R_s@1)": (g1 + r5) / 2, "arithmetic_mean": mean(r),
-           "harmonic_mean": harmonic_mean(r), "geometric_mean": geometric_mean(r)}
+           "harmonic_mean": harmonic_mean(r), "geometric_mean": _geometric_mean(r)}
     if _rank0():
         print(json.dumps(out, indent=4))
     return out
 
 
-def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dtype="bf16", index_cache=None):
+def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dtype="bf16", index_cache=None, gpu_preprocess=False,
+                      vit_depth=None):
     """FashionIQ evaluation (the reference calls this `clip_finetune_fiq`, blip_validate.py:26-98)."""
-    from .data_utils import FashionIQDataset, targetpad_transform
-    model, txt = _load(blip_model_name, backbone, model_path, dtype)
+    from .data_utils import FashionIQDataset
+    model, txt = _load(blip_model_name, backbone, model_path, dtype, vit_depth)
     model.eval()
-    preprocess = targetpad_transform(1.25, 224)
+    preprocess, workers = _preprocess(gpu_preprocess, model.device)
     r10s, r50s = [], []
     for d in val_dress_types:
         classic, relative = FashionIQDataset("val", [d], "classic", preprocess), FashionIQDataset("val", [d], "relative", preprocess)
         if _sharded():
             from .dist_eval import compute_fiq_val_metrics_sharded
-            r10, r50 = compute_fiq_val_metrics_sharded(relative, classic, model, txt)
+            r10, r50 = compute_fiq_val_metrics_sharded(relative, classic, model, txt, num_workers=workers)
         else:
-            feats, names = _gallery(classic, model, index_cache, f"fiq-val-{d}", backbone, dtype)
+            feats, names = _gallery(classic, model, index_cache, f"fiq-val-{d}", backbone, dtype, workers)
             r10, r50 = compute_fiq_val_metrics(relative, model, feats, names, txt)
         r10s.append(r10)
         r50s.append(r50)
@@ -136,13 +155,15 @@ def main(argv=None):
     p.add_argument("--model-path", type=str)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--index-cache", default=None, help="directory of gallery feature stores (sprc_amd/index.py): encode once, reuse")
+    p.add_argument("--gpu-preprocess", action="store_true", help="pad / bicubic resize / crop / normalise on the GPU (bit-identical to the PIL transform)")
+    p.add_argument("--vit-depth", type=int, default=None, help="truncate the ViT to N blocks (entry-point smoke tests only)")
     a = p.parse_args(argv)
     if a.dataset.lower() not in ("fashioniq", "cirr"):
         raise ValueError("Dataset should be either 'CIRR' or 'FashionIQ")
     if a.dataset.lower() == "cirr":
-        blip_validate_cirr(a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache)
-    else:
-        blip_validate_fiq(["dress", "toptee", "shirt"], a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache)
+        return blip_validate_cirr(a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache, a.gpu_preprocess, a.vit_depth)
+    return blip_validate_fiq(["dress", "toptee", "shirt"], a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache,
+                             a.gpu_preprocess, a.vit_depth)
 
 
 if __name__ == "__main__":

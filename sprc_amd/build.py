@@ -9,7 +9,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libsprc_hip.so"
-SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "rank.hip", "models.hip"]
+SOURCES = ["core.hip", "gemm.hip", "attention.hip", "rowops.hip", "rank.hip", "models.hip", "preprocess.hip"]
 # -fno-slp-vectorize: hipcc packs adjacent scalar fp32 ops into v_pk_fma_f32 / v_pk_mul_f32, which run SLOWER than the scalar
 # pairs on gfx950 (measured on the GEMM GELU epilogue: 117 us packed vs ~45 us scalar per ViT fc1 launch)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]

@@ -13,7 +13,7 @@ from .blip_validate import _load
 from .harness import extract_index_blip_features, generate_cirr_test_dicts
 
 
-def generate_cirr_test_submissions(file_name: str, blip_model, preprocess, txt_processors, rerank=False):
+def generate_cirr_test_submissions(file_name: str, blip_model, preprocess, txt_processors, rerank=False, num_workers: int = 2):
     from .data_utils import CIRRDataset, base_path
     import os
     classic = CIRRDataset("test1", "classic", preprocess)
@@ -24,7 +24,7 @@ def generate_cirr_test_submissions(file_name: str, blip_model, preprocess, txt_p
         if int(os.environ.get("RANK", "0")) != 0:
             return
     else:
-        feats, names = extract_index_blip_features(classic, blip_model)
+        feats, names = extract_index_blip_features(classic, blip_model, num_workers=num_workers)
         top, sub = generate_cirr_test_dicts(relative, blip_model, feats, names, txt_processors, rerank)
     submission = {"version": "rc2", "metric": "recall", **top}
     group_submission = {"version": "rc2", "metric": "recall_subset", **sub}
@@ -38,16 +38,19 @@ def generate_cirr_test_submissions(file_name: str, blip_model, preprocess, txt_p
 
 
 def main(argv=None):
-    from .data_utils import targetpad_transform
+    from .blip_validate import _preprocess
     p = ArgumentParser()
     p.add_argument("--blip-model-name", default="blip2_cir_align_prompt", type=str)
     p.add_argument("--model-path", type=str)
     p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
     p.add_argument("--rerank", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--gpu-preprocess", action="store_true", help="image transform on the GPU (bit-identical to the PIL transform)")
+    p.add_argument("--vit-depth", type=int, default=None, help="truncate the ViT to N blocks (entry-point smoke tests only)")
     a = p.parse_args(argv)
-    model, txt = _load(a.blip_model_name, a.backbone, a.model_path, a.dtype)
-    generate_cirr_test_submissions(f"{a.blip_model_name}_2", model, targetpad_transform(1.25, 224), txt, a.rerank)
+    model, txt = _load(a.blip_model_name, a.backbone, a.model_path, a.dtype, a.vit_depth)
+    preprocess, workers = _preprocess(a.gpu_preprocess, model.device)
+    generate_cirr_test_submissions(f"{a.blip_model_name}_2", model, preprocess, txt, a.rerank, workers)
 
 
 if __name__ == "__main__":

@@ -63,6 +63,51 @@ def targetpad_transform(target_ratio: float, dim: int) -> Callable:
     return tf
 
 
+class GpuTargetPad:
+    """`targetpad_transform(target_ratio, dim)` with the pixel work on the GPU (sprc_preprocess_targetpad): the host only
+    decodes (PIL) and hands over the uint8 RGB image; pad / bicubic resize / centre crop / normalise run as two HIP
+    kernels and are bit-identical to the PIL path above (tests/test_preprocess.py).  Returns a [3, dim, dim] fp32 tensor
+    on `device`.  Use with DataLoader(num_workers=0): the transform touches the GPU."""
+
+    on_device = True        # items are CUDA tensors: loaders must not pin them, and must run in the main process
+
+    def __init__(self, target_ratio: float, dim: int, device="cuda"):
+        import ctypes as C
+        from . import _lib as L
+        self.L, self.C = L, C
+        self.lib = L.load()
+        self.ratio, self.dim, self.device = float(target_ratio), int(dim), torch.device(device)
+        if self.device.type != "cuda":
+            raise L.SprcError("GpuTargetPad needs a GPU device (the PIL transform `targetpad_transform` is the host path)")
+        self.mean = (C.c_float * 3)(*CLIP_MEAN)
+        self.std = (C.c_float * 3)(*CLIP_STD)
+        self._ws = None
+
+    def __call__(self, image) -> torch.Tensor:
+        if not isinstance(image, (np.ndarray, torch.Tensor)):
+            image = np.asarray(image.convert("RGB"), dtype=np.uint8)       # _convert_image_to_rgb (data_utils.py:74-75)
+        src = torch.from_numpy(np.array(image, dtype=np.uint8, order="C")) if isinstance(image, np.ndarray) else image.contiguous()
+        if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
+            raise ValueError("expected a uint8 RGB image [H, W, 3]")
+        h, w = int(src.shape[0]), int(src.shape[1])
+        src = src.to(self.device, non_blocking=True)
+        need = int(self.lib.sprc_preprocess_workspace_bytes(h, w, self.ratio, self.dim))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((3, self.dim, self.dim), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            self.L.check(self.lib.sprc_preprocess_targetpad(src.data_ptr(), h, w, w * 3, self.ratio, self.dim, self.mean, self.std,
+                                                            out.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st),
+                         "sprc_preprocess_targetpad")
+        self._keep = src                                                    # the kernels read it asynchronously
+        return out
+
+
+def targetpad_transform_gpu(target_ratio: float, dim: int, device="cuda") -> Callable:
+    return GpuTargetPad(target_ratio, dim, device)
+
+
 class _Base(Dataset):
     def __getitem__(self, index):
         try:

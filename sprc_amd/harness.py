@@ -34,6 +34,13 @@ def collate_fn(batch: list):
     return torch.utils.data.dataloader.default_collate(batch)
 
 
+def _pin(dataset) -> bool:
+    """pin_memory for the loader unless the dataset's transform already returns device tensors (data_utils.GpuTargetPad)."""
+    while hasattr(dataset, "dataset"):              # torch.utils.data.Subset
+        dataset = dataset.dataset
+    return not getattr(getattr(dataset, "preprocess", None), "on_device", False)
+
+
 class RawStore:
     """`index_features[1]` when raw ViT embeddings are kept for a SUBSET of the gallery (the
     protocol returns raw[N,257,D] fp32 for every image, 1.45 MB each -- 3.3 GB for CIRR val, 1.4 TB for a 1 M gallery --
@@ -77,7 +84,7 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     keep_raw=True (the reference's behaviour): raw = the stacked [N,257,D] fp32 tensor.
     keep_raw=<collection of names> (or False): raw = a `RawStore` holding the embeddings of those images only
     (`raw_dtype=torch.bfloat16` halves them; they are cast back to fp32 when a query is fused)."""
-    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True, collate_fn=collate_fn)
+    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=_pin(dataset), collate_fn=collate_fn)
     feats, raws, names = [], [], []
     split = getattr(dataset, "split", "")
     print(f"extracting {type(dataset).__name__} {split} index features")
