@@ -33,7 +33,9 @@ extern "C" {
 enum { SPRC_OK = 0, SPRC_EINVAL = -1, SPRC_ELAUNCH = -2, SPRC_EWORKSPACE = -3, SPRC_EUNSUPPORTED = -4 };
 enum { SPRC_F32 = 0, SPRC_BF16 = 1,
        SPRC_F16 = 2 /* OUTPUT-only dtype of sprc_gemm: a residual-branch output ("delta") that sprc_layernorm adds to the
-                       fp32 residual stream (11-bit mantissa: 8x finer than the bf16 GEMM operands) */ };
+                       fp32 residual stream (11-bit mantissa: 8x finer than the bf16 GEMM operands) */,
+       SPRC_FP8 = 3 /* OCP e4m3fn (the gfx950 fp8; NOT MI300's fnuz): GEMM operands with a per-tensor activation scale and
+                       per-output-channel weight scales, fp32 accumulation (BASELINE.json config C5: "ViT-L, fp8 MFMA") */ };
 enum { SPRC_ACT_NONE = 0, SPRC_ACT_GELU = 1, SPRC_ACT_QUICKGELU = 2 };
 
 typedef void* sprc_stream;                    /* hipStream_t */
@@ -64,6 +66,9 @@ int sprc_prof_enable(int on);   /* 1 = start afresh, 0 = pause (records are kept
                                  * launch costs two stream markers (~7 us of pipeline bubble): sample steps, do not record all */
 int sprc_prof_collect(sprc_prof_entry* out /* [SPRC_K_COUNT] */);
 
+/* amax[0] = max(amax[0], max |x|) over n bf16 values (device float, caller-initialised): fp8 scale calibration. */
+int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s);
+
 /* fp32 -> bf16 (round-to-nearest-even) weight/feature packing. */
 int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s);
 
@@ -72,6 +77,7 @@ int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream
  * align_prompt.py:348,385.  A and W are `dtype`; bias/resid fp32; out is `out_dtype`.
  * K % 64 == 0 (bf16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (bf16) / 4 (f32) elements.
  * out_dtype SPRC_F16: bf16 operands only, no activation / residual / max32 (see sprc_layernorm_args.add16).
+ * dtype SPRC_FP8: K % 128 == 0; outputs bf16 / f32 (plain epilogue, residual allowed) or fp8 (any activation).
  *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
  * max32 != 0: "similarity" epilogue -- rows of A are query vectors, rows of W are gallery tokens (32 per
  * image); out[m*ldc + n/32] = max over the 32 W-rows of image n/32 (align_prompt.py:353-358). */
@@ -86,6 +92,10 @@ typedef struct {
     /* optional device scratch the call may use for split-K partial sums (never read afterwards); NULL/0 = none.
      * 8 * 128 * N * 4 bytes lets the <= 128 remainder rows of a K >= 4096 product be reduced by 8 workgroups per tile. */
     void* scratch;  size_t scratch_bytes;
+    /* dtype == SPRC_FP8:  out = act(a_scale * w_scale[n] * (A_q . W_q^T) + bias) + resid, A_q / W_q e4m3fn with
+     * A = a_scale * A_q (per tensor) and W[n,:] = w_scale[n] * W_q[n,:] (per output channel; fp32 [N], 16-byte aligned).
+     * out_dtype == SPRC_FP8: the result is multiplied by out_scale (= 1 / the consumer's a_scale) and saturated to +-448. */
+    const float* w_scale; float a_scale; float out_scale;
 } sprc_gemm_args;
 int sprc_gemm(const sprc_gemm_args* a, sprc_stream s);
 
@@ -113,6 +123,9 @@ typedef struct {
      * receives x + add16: the pre-LN residual-stream update. */
     const void* add16; int64_t ld_add;
     float* sum32;      int64_t ld_sum;
+    /* out_dtype == SPRC_FP8: y16 receives sat(LN(x) * y16_scale) as e4m3fn (ld16 in elements = bytes); y16_scale = 1 / the
+     * consumer GEMM's a_scale.  Not combinable with add16. */
+    float y16_scale;
 } sprc_layernorm_args;
 int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s);
 
@@ -201,6 +214,10 @@ typedef struct { const void* w; const float* b; } sprc_linear;   /* w: [out,in(p
 typedef struct {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     sprc_linear qkv, proj, fc1, fc2;            /* qkv bias: [q_bias, 0, v_bias] (eva_vit.py:120-122) */
+    /* fp8 ViT (sprc_vit_model.fp8 != 0): qkv / fc1 / fc2 weights are e4m3fn with per-output-channel scales, their inputs are
+     * quantised with the static per-tensor scales below (a = s * a_q); proj stays bf16 (its input is the attention output) */
+    const float *qkv_ws, *fc1_ws, *fc2_ws;      /* [3*width], [mlp], [width] fp32 */
+    float s_ln1, s_ln2, s_mlp;                  /* activation scales of the qkv / fc1 / fc2 inputs */
 } sprc_vit_layer;
 
 typedef struct {
@@ -210,6 +227,9 @@ typedef struct {
     const float *cls, *pos;                     /* [width], [tokens,width] */
     const float *ln_pre_w, *ln_pre_b, *ln_vision_w, *ln_vision_b;
     const sprc_vit_layer* layers;               /* host array [depth] */
+    int32_t fp8;                                /* 1: dtype is SPRC_BF16 and the three big GEMMs of every block run on fp8 operands */
+    float* calib_amax;                          /* optional device array [depth*3] (bf16 model only): running max |x| of the qkv / fc1 /
+                                                 * fc2 inputs, updated by sprc_vit_forward -- the calibration pass of the fp8 scales */
 } sprc_vit_model;
 
 typedef struct {

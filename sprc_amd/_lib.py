@@ -10,10 +10,10 @@ from pathlib import Path
 
 LIB_PATH = Path(__file__).resolve().parent / "libsprc_hip.so"
 
-SPRC_F32, SPRC_BF16, SPRC_F16 = 0, 1, 2          # SPRC_F16: GEMM output only (residual-branch deltas)
+SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: GEMM output only (residual deltas); FP8: OCP e4m3fn operands
 ABI_VERSION = 2
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
-DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16}
+DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16, "fp8": SPRC_BF16}     # "fp8" engine: bf16 model + fp8 ViT GEMMs
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -26,13 +26,14 @@ class GemmArgs(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("dtype", i32), ("out_dtype", i32), ("act", i32), ("max32", i32),
                 ("A", vp), ("lda", i64), ("amap", RowMap), ("W", vp), ("ldw", i64), ("bias", vp),
                 ("resid", vp), ("ldr", i64), ("C", vp), ("ldc", i64), ("cmap", RowMap),
-                ("scratch", vp), ("scratch_bytes", C.c_size_t)]
+                ("scratch", vp), ("scratch_bytes", C.c_size_t), ("w_scale", vp), ("a_scale", f32), ("out_scale", f32)]
 
 
 class LayerNormArgs(C.Structure):
     _fields_ = [("M", i32), ("D", i32), ("out_dtype", i32), ("x", vp), ("ldx", i64), ("xmap", RowMap),
                 ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("ld32", i64), ("ymap", RowMap),
-                ("y16", vp), ("ld16", i64), ("add16", vp), ("ld_add", i64), ("sum32", vp), ("ld_sum", i64)]
+                ("y16", vp), ("ld16", i64), ("add16", vp), ("ld_add", i64), ("sum32", vp), ("ld_sum", i64),
+                ("y16_scale", f32)]
 
 
 class AttentionArgs(C.Structure):
@@ -61,7 +62,8 @@ class Linear(C.Structure):
 
 class VitLayer(C.Structure):
     _fields_ = [("ln1_w", vp), ("ln1_b", vp), ("ln2_w", vp), ("ln2_b", vp),
-                ("qkv", Linear), ("proj", Linear), ("fc1", Linear), ("fc2", Linear)]
+                ("qkv", Linear), ("proj", Linear), ("fc1", Linear), ("fc2", Linear),
+                ("qkv_ws", vp), ("fc1_ws", vp), ("fc2_ws", vp), ("s_ln1", f32), ("s_ln2", f32), ("s_mlp", f32)]
 
 
 class VitModel(C.Structure):
@@ -69,7 +71,7 @@ class VitModel(C.Structure):
                 ("act", i32), ("tokens", i32), ("patch_size", i32), ("image", i32), ("patch_k_pad", i32),
                 ("has_ln_pre", i32), ("ln_eps", f32), ("ln_vision_eps", f32), ("patch", Linear),
                 ("cls", vp), ("pos", vp), ("ln_pre_w", vp), ("ln_pre_b", vp), ("ln_vision_w", vp), ("ln_vision_b", vp),
-                ("layers", C.POINTER(VitLayer))]
+                ("layers", C.POINTER(VitLayer)), ("fp8", i32), ("calib_amax", vp)]
 
 
 class QfLayer(C.Structure):
@@ -95,6 +97,7 @@ SIGNATURES = {
     "sprc_prof_enable": (i32, [i32]),
     "sprc_prof_collect": (i32, [C.POINTER(ProfEntry)]),
     "sprc_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
+    "sprc_absmax_bf16": (i32, [vp, sz, vp, vp]),
     "sprc_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "sprc_gemm_pair": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
     "sprc_layernorm": (i32, [C.POINTER(LayerNormArgs), vp]),

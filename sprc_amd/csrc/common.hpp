@@ -75,7 +75,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
-static inline size_t dtype_size(int dt) { return (dt == SPRC_BF16 || dt == SPRC_F16) ? 2 : 4; }
+static inline size_t dtype_size(int dt) { return dt == SPRC_FP8 ? 1 : (dt == SPRC_BF16 || dt == SPRC_F16) ? 2 : 4; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace sprc

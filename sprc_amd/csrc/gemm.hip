@@ -48,6 +48,8 @@ struct GemmParams {
     const char* W2; const float* bias2; int a_off2, c_off2;      // what differs in the second product: weight, bias, row-map offsets
     int ksplit;                         // > 1: split-K launch of the 128x128 kernel (grid = tiles x ksplit), raw fp32 partials
     int64_t split_stride;               // elements between the partial planes of consecutive K splits
+    const float* w_scale; float a_scale;     // fp8 operands: acc * (a_scale * w_scale[n]) before the bias (null: no scaling)
+    float out_scale;                    // fp8 output: value * out_scale before the conversion (1 / the consumer's dequantisation scale)
     int debug;                          // SPRC_GEMM_DEBUG, timing experiments on the 256x256 kernel (results are WRONG with 1 / 2):
                                         //   1 no global->LDS loads   2 no fragment reads   64 s_memtime stamp build (tools/gemm_stamp.py)
                                         //   512 all four loads of an interval pair in the NC interval   1024 no residual prefetch
@@ -73,6 +75,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 typedef _Float16 f16_t;
+struct fp8_t { uint8_t bits; };        // OCP e4m3fn (gfx950), operand / output tag type
+
+// saturating fp32 -> 2 x e4m3fn (v_cvt_pk_fp8_f32: RNE; inputs clamped to +-448 first, the format has no infinity)
+__device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, bool hi) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f);
+    b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
+}
 // 4 consecutive outputs of one row: 16 B (fp32) or 8 B (bf16 / fp16)
 template <typename OutT>
 __device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v) {
@@ -81,15 +91,25 @@ __device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v) {
     } else if constexpr (std::is_same<OutT, f16_t>::value) {
         typedef __attribute__((ext_vector_type(4))) _Float16 half4;
         *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    } else if constexpr (std::is_same<OutT, fp8_t>::value) {
+        *reinterpret_cast<uint32_t*>(dst) = pack_fp8x2(v[2], v[3], pack_fp8x2(v[0], v[1], 0u, false), true);
     } else {
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
         *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
     }
 }
 
+// one output element (the ragged-N scalar path)
+template <typename OutT>
+__device__ __forceinline__ void store_out1(OutT* dst, float v) {
+    if constexpr (std::is_same<OutT, fp8_t>::value) dst->bits = (uint8_t)(pack_fp8x2(v, 0.f, 0u, false) & 0xffu);
+    else *dst = (OutT)v;
+}
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
 template <> struct Frag<float> { typedef f32x4 type; };
+template <> struct Frag<fp8_t> { typedef u32x4 type; };       // unused: the fp8 main loop is the hand-pipelined one
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -127,7 +147,19 @@ __device__ __forceinline__ void wait_lgkmcnt() {
 // One K-tile (4 MFMA k-steps) of a wave's TM x TN accumulator block, hand software-pipelined.
 // a_base / b_base: LDS byte address of this lane's first A / W row in the current stage; c0 = swizzled slot of
 // k-step 0 ((half ^ f(row)) << 4); k-step kk reads slot c0 ^ (kk << 5).
-template <int TM, int TN, int KT_BYTES, typename Issue>
+// fp8 (FP8 = true): a 16-B fragment holds 16 k-values = TWO e4m3 MFMA k-steps (low / high 8 bytes); which bytes form a
+// k-step is a free permutation of k as long as both operands use the same one, so the LDS layout and the reads are the bf16 ones.
+__device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x16 c, std::false_type) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x16 c, std::true_type) {
+    const long b0 = (long)(((uint64_t)b[1] << 32) | b[0]), b1 = (long)(((uint64_t)b[3] << 32) | b[2]);
+    const long a0 = (long)(((uint64_t)a[1] << 32) | a[0]), a1 = (long)(((uint64_t)a[3] << 32) | a[2]);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b0, a0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b1, a1, c, 0, 0, 0);
+}
+
+template <int TM, int TN, int KT_BYTES, bool FP8, typename Issue>
 __device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base, uint32_t c0, f32x16 (&acc)[TM][TN],
                                                 Issue&& issue) {
     static_assert(KT_BYTES == 128, "4 k-steps per K-tile");
@@ -152,8 +184,7 @@ __device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cur][ni]),
-                                                                      __builtin_bit_cast(bf16x8, fa[cur][mi]), acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = mfma_frag(fb[cur][ni], fa[cur][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
         __builtin_amdgcn_s_setprio(0);
     });
 }
@@ -208,6 +239,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             const bool col_ok = col < p.N;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+            f32x4 sv = {1.f, 1.f, 1.f, 1.f};               // fp8 operands: per-output-channel dequantisation
+            const bool scaled = p.w_scale != nullptr;
+            if (scaled && col_ok) {
+                sv = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[e] *= p.a_scale;
+            }
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi) {
                 // residual rows of this block first (C may alias it: every element is read by the lane that writes it)
@@ -233,13 +271,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + rsub) * LD + ch * 16);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {           // element-wise on purpose: vector adds become v_pk_add_f32 (slower)
+                        if (scaled) v[e] *= sv[e];
                         v[e] += bv[e];
                         if constexpr (ACT == SPRC_ACT_GELU) {
-                            if constexpr (sizeof(T) == 2) v[e] = gelu_fast(v[e]);
+                            if constexpr (sizeof(T) <= 2) v[e] = gelu_fast(v[e]);
                             else v[e] = gelu_erf(v[e]);
                         }
                         if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
                         v[e] += rv[it][e];
+                        if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= p.out_scale;
                     }
                     if (!ok[it]) continue;
                     store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + prow[it] * p.ldc + col, v);
@@ -275,14 +315,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     for (int r = 0; r < 16; ++r) {
                         const int col = cn0 + (wc * TN + ni) * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
                         if (!(row_ok && col < p.N)) continue;
-                        float v = acc[mi][ni][r] + (p.bias ? p.bias[col] : 0.f);
+                        float v = acc[mi][ni][r];
+                        if (p.w_scale != nullptr) v *= p.a_scale * p.w_scale[col];
+                        v += (p.bias ? p.bias[col] : 0.f);
                         if constexpr (ACT == SPRC_ACT_GELU) {
-                            if constexpr (sizeof(T) == 2) v = gelu_fast(v);
+                            if constexpr (sizeof(T) <= 2) v = gelu_fast(v);
                             else v = gelu_erf(v);
                         }
                         if constexpr (ACT == SPRC_ACT_QUICKGELU) v = quick_gelu(v);
                         if (rrow != nullptr) v += rrow[col];
-                        crow[col] = (OutT)v;
+                        if constexpr (std::is_same<OutT, fp8_t>::value) v *= p.out_scale;
+                        store_out1<OutT>(crow + col, v);
                     }
             }
         }
@@ -372,10 +415,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
             __syncthreads();                 // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free again
             const bool more = t + 1 < nt;
             const int64_t ko = kbase + (int64_t)(t + 1) * KT_BYTES;
-            if constexpr (sizeof(T) == 2) {
+            if constexpr (sizeof(T) <= 2) {
                 char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
                 const uint32_t so = lds0 + (t & 1) * STAGE_BYTES;
-                pipe_ktile_bf16<TM, TN, KT_BYTES>(so + a_off, so + b_off, c0, acc, [&](auto kk_) {
+                pipe_ktile_bf16<TM, TN, KT_BYTES, sizeof(T) == 1>(so + a_off, so + b_off, c0, acc, [&](auto kk_) {
                     constexpr int kk = decltype(kk_)::value;
                     if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
                 });
@@ -424,7 +467,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
 template <typename OutT, int ACT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t stride, int M, int N,
                                                             const float* __restrict__ bias, const float* resid, int64_t ldr,
-                                                            OutT* C, int64_t ldc) {
+                                                            OutT* C, int64_t ldc, const float* __restrict__ w_scale, float a_scale,
+                                                            float out_scale) {
     const int n4 = N / 4;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)M * n4) return;
@@ -437,11 +481,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        if (w_scale != nullptr) v[e] *= a_scale * w_scale[col + e];
         if (bias != nullptr) v[e] += bias[col + e];
         if constexpr (ACT == SPRC_ACT_GELU) v[e] = gelu_fast(v[e]);
         if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
         if (resid != nullptr) v[e] += resid[(int64_t)row * ldr + col + e];
-        C[(int64_t)row * ldc + col + e] = (OutT)v[e];
+        if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= out_scale;
+        store_out1<OutT>(C + (int64_t)row * ldc + col + e, v[e]);
     }
 }
 
@@ -472,17 +518,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 //        G0 after C(t,1) (4t+3: B0 B1 of t+1) and after NC(t,0) (4t: A2 A3 of t); G1 after NC(t,1) (4t+3: A0 A1 B2 B3 of
 //        t+1).  Every piece has >= 2 intervals between issue and wait.
 //   WAR  a piece is restaged >= 1 interval after the barrier that followed the last read of the region it overwrites.
-template <typename OutT, int ACT, bool MAX32, bool STAMP = false>
+template <typename OutT, int ACT, bool MAX32, bool STAMP = false, bool FP8 = false>
 __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef bf16_t T;
+    typedef typename std::conditional<FP8, fp8_t, bf16_t>::type T;
     constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
     constexpr int BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * KTB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = __builtin_amdgcn_readfirstlane(wave / WN), wc = wave % WN;   // wr doubles as the phase group (SGPR: barriers under it)
     const int r32 = lane & 31, half = lane >> 5;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int nt = p.K / 64;
+    const int nt = FP8 ? p.K / 128 : p.K / 64;             // K-tiles of 128 bytes
     uint64_t tile_ts[4] = {0, 0, 0, 0};                      // STAMP build: entry | prologue done | K loop done | epilogue done
     if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
 
@@ -555,8 +601,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         __builtin_amdgcn_s_setprio(1);
         static_for<0, 16>([&](auto x_) {
             constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[k][ni]),
-                                                                  __builtin_bit_cast(bf16x8, fa[k][mi]), acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
             if constexpr (x == 7) { if (tile >= 0) load_piece(q_, I1{}, tile); }
         });
         __builtin_amdgcn_s_setprio(0);
@@ -684,15 +729,30 @@ static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? (int)strtol(e, nullptr, 0) : dflt;
 }
-static int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
+constexpr int MAX_DEVICES = 64;
+static int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < MAX_DEVICES ? dev : 0;
+}
+static int num_cus() {                      // per device: a process may drive several GPUs
+    static int n[MAX_DEVICES] = {0};
+    const int dev = current_device();
+    if (n[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+        if (n[dev] <= 0) n[dev] = 256;
     }
-    return n;
+    return n[dev];
+}
+// hipFuncSetAttribute applies to the function ON THE CURRENT DEVICE: opt in once per (kernel instantiation, device)
+template <typename K>
+static void optin_lds(K kern, int bytes, bool (&done)[MAX_DEVICES]) {
+    const int dev = current_device();
+    if (!done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done[dev] = true;
+    }
 }
 
 template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT>
@@ -702,11 +762,8 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     // measured equal to one workgroup per tile on MI355X while costing ~45 VGPRs: all tiles take the same time, so the
     // CUs stay in lockstep and the output-write bursts still coincide.  Removed.)
     auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static bool attr_set[MAX_DEVICES] = {false};
+    optin_lds(kern, LDS, attr_set);
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     static const int order = env_int("SPRC_GEMM_ORDER", 0);     // 8-m grouped order is better for the K-heavy 128x128 GEMMs
@@ -718,11 +775,12 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     return SPRC_OK;
 }
 
-template <typename OutT, int ACT, bool MAX32>
+template <typename T, typename OutT, int ACT, bool MAX32>
 static int launch_anti(GemmParams p, hipStream_t st) {
     constexpr int LDS = 2 * 512 * 128;
-    auto kern = gemm_anti_kernel<OutT, ACT, MAX32>;
-    if constexpr (sizeof(OutT) == 2 && ACT == SPRC_ACT_NONE && !MAX32) {
+    constexpr bool FP8 = sizeof(T) == 1;
+    auto kern = gemm_anti_kernel<OutT, ACT, MAX32, false, FP8>;
+    if constexpr (std::is_same<OutT, bf16_t>::value && ACT == SPRC_ACT_NONE && !MAX32 && !FP8) {
         if ((p.debug & 64) && p.resid != nullptr) {         // phase-timestamp build (tools/gemm_stamp.py)
             auto sk = gemm_anti_kernel<OutT, ACT, MAX32, true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -735,11 +793,8 @@ static int launch_anti(GemmParams p, hipStream_t st) {
             return SPRC_OK;
         }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static bool attr_set[MAX_DEVICES] = {false};
+    optin_lds(kern, LDS, attr_set);
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     static const int order = env_int("SPRC_GEMM_ORDER", 4);     // W-resident groups of 4 n-tiles: +8 % on N = 9216, neutral else
@@ -761,7 +816,7 @@ template <typename T, typename OutT, int ACT, bool MAX32>
 static int launch(const GemmParams& p, hipStream_t st) {
     static const int forced = env_int("SPRC_GEMM_TILE", 0);
     int cfg = forced;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) <= 2) {
         if (cfg == 0) {
             // Cost model in units of one 256x256xK tile on a CU (measured on MI355X, tools/gemm_shapes.py):
             //   B  256x256 anti-phase kernel, one WG per CU:            rounds x 1
@@ -804,7 +859,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
                 pt.A = p.A + (int64_t)Mm * p.lda_b;
                 pt.C = reinterpret_cast<char*>(p.C) + (int64_t)Mm * p.ldc * (MAX32 ? 4 : (int64_t)sizeof(OutT));
                 if (p.resid != nullptr) pt.resid = p.resid + (int64_t)Mm * p.ldr;
-                const int rc = launch_anti<OutT, ACT, MAX32>(pm, st);
+                const int rc = launch_anti<T, OutT, ACT, MAX32>(pm, st);
                 if (rc != SPRC_OK) return rc;
                 // remainder rows: a long reduction on a handful of workgroups is latency-bound (11 WGs x 96 K-tiles = 77 us
                 // for the ViT fc2) -> split K over 8 workgroups per tile into caller scratch and reduce in a fixed order
@@ -812,14 +867,14 @@ static int launch(const GemmParams& p, hipStream_t st) {
                 if (rem <= 128 && p.K >= 4096 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.scratch != nullptr &&
                     p.scratch_elems >= (int64_t)S * rem * p.N) {
                     GemmParams ps = pt;
-                    ps.C = p.scratch; ps.ldc = p.N; ps.bias = nullptr; ps.resid = nullptr; ps.ldr = 0;
+                    ps.C = p.scratch; ps.ldc = p.N; ps.bias = nullptr; ps.resid = nullptr; ps.ldr = 0; ps.w_scale = nullptr;
                     ps.ksplit = S; ps.split_stride = (int64_t)rem * p.N;
                     const int rs = launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 2>(ps, st);
                     if (rs != SPRC_OK) return rs;
                     const int64_t n = (int64_t)rem * (p.N / 4);
                     hipLaunchKernelGGL((splitk_reduce_kernel<OutT, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                        p.scratch, S, ps.split_stride, rem, p.N, p.bias, pt.resid, p.ldr,
-                                       reinterpret_cast<OutT*>(pt.C), p.ldc);
+                                       reinterpret_cast<OutT*>(pt.C), p.ldc, p.w_scale, p.a_scale, p.out_scale);
                     SPRC_CHECK_LAUNCH("sprc_gemm(split-K reduce)");
                     return SPRC_OK;
                 }
@@ -828,7 +883,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
             cfg = cB <= cA ? 4 : 2;
         }
         // 256x256 tile: anti-phase schedule by default (SPRC_GEMM_TILE=14 forces the lock-step kernel for A/B runs)
-        if (cfg == 4 || cfg == 10) return launch_anti<OutT, ACT, MAX32>(p, st);
+        if (cfg == 4 || cfg == 10) return launch_anti<T, OutT, ACT, MAX32>(p, st);
     } else {
         if (cfg == 0) cfg = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024 ? 4 : 2;
     }
@@ -838,10 +893,25 @@ static int launch(const GemmParams& p, hipStream_t st) {
 
 template <typename T>
 static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st) {
-    if (a->max32) return launch<T, float, SPRC_ACT_NONE, true>(p, st);
+    if constexpr (sizeof(T) != 1) { if (a->max32) return launch<T, float, SPRC_ACT_NONE, true>(p, st); }
     if (a->out_dtype == SPRC_F16) {                     // residual-branch delta (validated by the caller: bf16 operands, plain epilogue)
         if constexpr (sizeof(T) == 2) return launch<T, f16_t, SPRC_ACT_NONE, false>(p, st);
         else { set_error("sprc_gemm: SPRC_F16 output needs bf16 operands"); return SPRC_EUNSUPPORTED; }
+    }
+    if constexpr (sizeof(T) == 1) {                     // fp8 operands: the three epilogues of the fp8 ViT path
+        if (a->out_dtype == SPRC_FP8) {
+            switch (a->act) {
+                case SPRC_ACT_NONE: return launch<T, fp8_t, SPRC_ACT_NONE, false>(p, st);
+                case SPRC_ACT_GELU: return launch<T, fp8_t, SPRC_ACT_GELU, false>(p, st);
+                case SPRC_ACT_QUICKGELU: return launch<T, fp8_t, SPRC_ACT_QUICKGELU, false>(p, st);
+            }
+        }
+        if (a->act == SPRC_ACT_NONE && a->out_dtype == SPRC_BF16) return launch<T, bf16_t, SPRC_ACT_NONE, false>(p, st);
+        if (a->act == SPRC_ACT_NONE && a->out_dtype == SPRC_F32) return launch<T, float, SPRC_ACT_NONE, false>(p, st);
+        set_error("sprc_gemm(fp8): unsupported epilogue (act %d, out_dtype %d)", a->act, a->out_dtype);
+        return SPRC_EUNSUPPORTED;
+    } else {
+        if (a->out_dtype == SPRC_FP8) { set_error("sprc_gemm: SPRC_FP8 output needs fp8 operands"); return SPRC_EUNSUPPORTED; }
     }
     const bool o16 = a->out_dtype == SPRC_BF16;
     switch (a->act) {
@@ -863,8 +933,12 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     using namespace sprc;
     SPRC_REQUIRE(a != nullptr, "sprc_gemm: null args");
     SPRC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "sprc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
-    SPRC_REQUIRE(a->dtype == SPRC_BF16 || a->dtype == SPRC_F32, "sprc_gemm: bad dtype %d", a->dtype);
-    SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32 || a->out_dtype == SPRC_F16, "sprc_gemm: bad out_dtype %d", a->out_dtype);
+    SPRC_REQUIRE(a->dtype == SPRC_BF16 || a->dtype == SPRC_F32 || a->dtype == SPRC_FP8, "sprc_gemm: bad dtype %d", a->dtype);
+    SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32 || a->out_dtype == SPRC_F16 || a->out_dtype == SPRC_FP8,
+                 "sprc_gemm: bad out_dtype %d", a->out_dtype);
+    SPRC_REQUIRE(a->dtype != SPRC_FP8 || (a->w_scale != nullptr && a->a_scale > 0.f && !a->max32 && b == nullptr),
+                 "sprc_gemm(fp8): needs w_scale, a_scale > 0; no max32 / paired launch");
+    SPRC_REQUIRE(a->out_dtype != SPRC_FP8 || a->out_scale > 0.f, "sprc_gemm: SPRC_FP8 output needs out_scale > 0");
     SPRC_REQUIRE(a->out_dtype != SPRC_F16 || (a->dtype == SPRC_BF16 && a->act == SPRC_ACT_NONE && !a->resid && !a->max32),
                  "sprc_gemm: SPRC_F16 output takes bf16 operands and a plain (bias-only) epilogue");
     const int es = (int)dtype_size(a->dtype);
@@ -911,14 +985,16 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
         p.a_off2 = b->amap.group_offset; p.c_off2 = b->cmap.group_offset;
     }
     p.scratch = reinterpret_cast<float*>(a->scratch); p.scratch_elems = (int64_t)(a->scratch_bytes / 4);
+    p.w_scale = a->dtype == SPRC_FP8 ? a->w_scale : nullptr; p.a_scale = a->a_scale; p.out_scale = a->out_scale;
     static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
     p.debug = dbg;
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     hipStream_t st = (hipStream_t)s;
     const double osz = a->max32 ? 4.0 / 32.0 : (double)dtype_size(a->out_dtype);
     const double np = b != nullptr ? 2.0 : 1.0;
-    ProfScope prof(a->dtype == SPRC_BF16 ? SPRC_K_GEMM_BF16 : SPRC_K_GEMM_F32, st, np * 2.0 * a->M * (double)a->N * a->K,
+    ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * a->K,
                    np * (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))));
+    if (a->dtype == SPRC_FP8) return dispatch<fp8_t>(a, p, st);
     return a->dtype == SPRC_BF16 ? dispatch<bf16_t>(a, p, st) : dispatch<float>(a, p, st);
 }
 

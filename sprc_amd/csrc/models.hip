@@ -23,11 +23,15 @@ struct Bump {
 
 static const sprc_rowmap ID_MAP = {0, 0, 0};
 
+struct Fp8Scales { const float* w_scale; float a_scale, out_scale; };
+
 static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
                 void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0,
-                sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0) {
+                sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0,
+                const Fp8Scales* q = nullptr) {
     sprc_gemm_args g;
     memset(&g, 0, sizeof(g));
+    if (q != nullptr) { g.w_scale = q->w_scale; g.a_scale = q->a_scale; g.out_scale = q->out_scale; }
     g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
     g.A = A; g.lda = lda; g.amap = amap;
     g.W = w.w; g.ldw = K; g.bias = w.b;
@@ -55,7 +59,8 @@ static int gemm2(hipStream_t st, int dt, int out_dt, int M, int N, int K, const 
 
 // y = LN(x [+ add16]); sum32 (optional) receives x + add16 (the residual-stream update of a pre-LN block)
 static int lnorm(hipStream_t st, int dt, int M, int D, const float* x, const float* gam, const float* bet, float eps,
-                 float* y32, void* y16, sprc_rowmap map = ID_MAP, const void* add16 = nullptr, float* sum32 = nullptr) {
+                 float* y32, void* y16, sprc_rowmap map = ID_MAP, const void* add16 = nullptr, float* sum32 = nullptr,
+                 float y16_scale = 0.f) {
     sprc_layernorm_args a;
     memset(&a, 0, sizeof(a));
     a.M = M; a.D = D; a.out_dtype = dt;
@@ -65,6 +70,7 @@ static int lnorm(hipStream_t st, int dt, int M, int D, const float* x, const flo
     a.y16 = y16; a.ld16 = D;
     a.add16 = add16; a.ld_add = D;
     a.sum32 = sum32; a.ld_sum = D;
+    a.y16_scale = y16_scale;
     return sprc_layernorm(&a, st);
 }
 
@@ -351,11 +357,32 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     // that reads x next: the branch GEMM writes its output as fp16 into the h buffer (dead at that point; the LN overwrites
     // it in place with its bf16 result) and the LN kernel adds it to the fp32 residual stream (sum32 = x) before the
     // statistics.  Off by default (see fuse_add_enabled: no net gain, and it costs parity).
-    const bool fuse_add = dt == SPRC_BF16 && fuse_add_enabled();
+    const bool fp8 = m->fp8 != 0;
+    const bool fuse_add = dt == SPRC_BF16 && !fp8 && fuse_add_enabled();
+    SPRC_REQUIRE(!fp8 || (dt == SPRC_BF16 && D % 128 == 0 && F % 128 == 0), "sprc_vit_forward: the fp8 path needs a bf16 model with width, mlp %% 128 == 0");
+    SPRC_REQUIRE(!(fp8 && m->calib_amax), "sprc_vit_forward: calibrate on the bf16 model, not on the fp8 one");
+    float* calib = (dt == SPRC_BF16 && !fp8) ? m->calib_amax : nullptr;
     for (int l = 0; l < m->depth; ++l) {                    // enqueue layer by layer, alternating streams: both stay fed
         const sprc_vit_layer& L = m->layers[l];
         for (int i = 0; i < nparts; ++i) {
             const Part& q = parts[i];
+            if (fp8) {
+                // fp8 ViT block: LN -> e4m3 operand (static scale), qkv / fc1 / fc2 on fp8 MFMA with per-channel weight scales,
+                // fc1's GELU output quantised in its epilogue; attention and proj stay bf16; residual stream / LN fp32.
+                // h (bf16-sized) holds the fp8 operand: half its bytes, leading dimension D bytes.
+                const Fp8Scales s_qkv{L.qkv_ws, L.s_ln1, 0.f}, s_fc1{L.fc1_ws, L.s_ln2, 1.0f / L.s_mlp}, s_fc2{L.fc2_ws, L.s_mlp, 0.f};
+                RUN(lnorm(q.ps, SPRC_FP8, q.Mp, D, q.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, q.h, ID_MAP, nullptr, nullptr, 1.0f / L.s_ln1));
+                RUN(gemm(q.ps, SPRC_FP8, SPRC_BF16, q.Mp, 3 * D, D, q.h, D, L.qkv, q.qkv, 3 * D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP,
+                         nullptr, 0, &s_qkv));
+                RUN(attn(q.ps, dt, q.Bp, m->heads, T, T, m->head_dim, q.qkv, 3 * D, q.qkv + D * es, 3 * D, q.qkv + 2 * D * es, 3 * D,
+                         q.ctx, D, nullptr, scale));
+                RUN(gemm(q.ps, dt, SPRC_F32, q.Mp, D, D, q.ctx, D, L.proj, q.x, D, SPRC_ACT_NONE, q.x, D));
+                RUN(lnorm(q.ps, SPRC_FP8, q.Mp, D, q.x, L.ln2_w, L.ln2_b, m->ln_eps, nullptr, q.h, ID_MAP, nullptr, nullptr, 1.0f / L.s_ln2));
+                RUN(gemm(q.ps, SPRC_FP8, SPRC_FP8, q.Mp, F, D, q.h, D, L.fc1, q.mlp, F, m->act, nullptr, 0, ID_MAP, ID_MAP, nullptr, 0, &s_fc1));
+                RUN(gemm(q.ps, SPRC_FP8, SPRC_F32, q.Mp, D, F, q.mlp, F, L.fc2, q.x, D, SPRC_ACT_NONE, q.x, D, ID_MAP, ID_MAP, q.scratch,
+                         scratch_bytes, &s_fc2));
+                continue;
+            }
             if (fuse_add) {
                 const bool pend = l > 0;                    // fc2 output of the previous layer waits in h
                 RUN(lnorm(q.ps, dt, q.Mp, D, q.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, q.h, ID_MAP, pend ? q.h : nullptr,
@@ -363,6 +390,7 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
             } else {
                 RUN(lnorm(q.ps, dt, q.Mp, D, q.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, q.h));
             }
+            if (calib) RUN(sprc_absmax_bf16(q.h, (size_t)q.Mp * D, calib + l * 3 + 0, q.ps));
             RUN(gemm(q.ps, dt, dt, q.Mp, 3 * D, D, q.h, D, L.qkv, q.qkv, 3 * D));
             RUN(attn(q.ps, dt, q.Bp, m->heads, T, T, m->head_dim, q.qkv, 3 * D, q.qkv + D * es, 3 * D, q.qkv + 2 * D * es, 3 * D,
                      q.ctx, D, nullptr, scale));
@@ -373,7 +401,9 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
                 RUN(gemm(q.ps, dt, SPRC_F32, q.Mp, D, D, q.ctx, D, L.proj, q.x, D, SPRC_ACT_NONE, q.x, D));
                 RUN(lnorm(q.ps, dt, q.Mp, D, q.x, L.ln2_w, L.ln2_b, m->ln_eps, nullptr, q.h));
             }
+            if (calib) RUN(sprc_absmax_bf16(q.h, (size_t)q.Mp * D, calib + l * 3 + 1, q.ps));
             RUN(gemm(q.ps, dt, dt, q.Mp, F, D, q.h, D, L.fc1, q.mlp, F, m->act));
+            if (calib) RUN(sprc_absmax_bf16(q.mlp, (size_t)q.Mp * F, calib + l * 3 + 2, q.ps));
             if (fuse_add) {
                 RUN(gemm(q.ps, dt, SPRC_F16, q.Mp, D, F, q.mlp, F, L.fc2, q.h, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP, q.scratch,
                          scratch_bytes));

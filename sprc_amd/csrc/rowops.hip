@@ -114,6 +114,53 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams
                     p.y16 ? (char*)p.y16 + yr * p.ld16 * (BF16 ? 2 : 4) : nullptr, nch, lane);
 }
 
+// LayerNorm whose operand copy is e4m3fn: y8 = sat(LN(x) * q_scale)  (q_scale = 1 / the consumer GEMM's a_scale)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, lo, true);
+}
+
+__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_fp8_kernel(LnParams p, float q_scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nch = p.D >> 2;
+    RowRegs r;
+    const int64_t xr = map_row(p.xmap, row);
+    load_row(r, p.x + xr * p.ldx, nch, lane);
+    layernorm_regs(r, nch, p.D, lane, p.gamma, p.beta, p.eps);
+    const int64_t yr = map_row(p.ymap, row);
+    if (p.y32) store_row<false>(r, p.y32 + yr * p.ld32, nullptr, nch, lane);
+    uint32_t* y8 = reinterpret_cast<uint32_t*>((char*)p.y16 + yr * p.ld16);
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nch) y8[i] = pack_fp8x4(r.v[c].x * q_scale, r.v[c].y * q_scale, r.v[c].z * q_scale, r.v[c].w * q_scale);
+    }
+}
+
+// amax[0] = max(amax[0], max |x|) over a bf16 tensor (calibration of the fp8 activation scales; values are >= 0, so the
+// integer ordering of the fp32 bit patterns is the numeric one and atomicMax on the bits is exact)
+__global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t* __restrict__ x, size_t n, float* amax) {
+    float m = 0.f;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (size_t)gridDim.x * 256 * 8) {
+        if (i + 8 <= n) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(x + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m = fmaxf(m, fabsf(__uint_as_float(v[e] << 16)));
+                m = fmaxf(m, fabsf(__uint_as_float(v[e] & 0xffff0000u)));
+            }
+        } else {
+            for (size_t j = i; j < n; ++j) m = fmaxf(m, fabsf(bf16_bits_to_f32(x[j])));
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc_qformer_embed_args p) {
     const int lane = threadIdx.x & 63;
@@ -252,7 +299,11 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
     ProfScope prof(SPRC_K_ROWOPS, (hipStream_t)s, 8.0 * a->M * (double)a->D,
                    (double)a->M * a->D * (4.0 + (a->y32 ? 4.0 : 0.0) + (a->y16 ? (double)dtype_size(a->out_dtype) : 0.0) +
                                           (a->add16 ? 2.0 : 0.0) + (a->sum32 ? 4.0 : 0.0)));
-    if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, (hipStream_t)s, p);
+    if (a->out_dtype == SPRC_FP8) {
+        SPRC_REQUIRE(a->y16 != nullptr && a->y16_scale > 0.f && a->add16 == nullptr && ((uintptr_t)a->y16 % 4) == 0,
+                     "sprc_layernorm(fp8): needs y16, y16_scale > 0 and no fused add");
+        hipLaunchKernelGGL(layernorm_fp8_kernel, grid, block, 0, (hipStream_t)s, p, a->y16_scale);
+    } else if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, (hipStream_t)s, p);
     else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, (hipStream_t)s, p);
     SPRC_CHECK_LAUNCH("sprc_layernorm");
     return SPRC_OK;
@@ -351,5 +402,14 @@ extern "C" int sprc_qformer_mask(const int64_t* attention_mask, float* out, int3
     const int n = B * (Lq + Lt);
     hipLaunchKernelGGL(qformer_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)s, attention_mask, out, B, Lq, Lt);
     SPRC_CHECK_LAUNCH("sprc_qformer_mask");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s) {
+    SPRC_REQUIRE(x && amax && n > 0 && ((uintptr_t)x % 16) == 0, "sprc_absmax_bf16: bad arguments");
+    const size_t blocks = (n / 8 + 255) / 256;
+    hipLaunchKernelGGL(absmax_bf16_kernel, dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, (hipStream_t)s,
+                       reinterpret_cast<const uint16_t*>(x), n, amax);
+    SPRC_CHECK_LAUNCH("sprc_absmax_bf16");
     return SPRC_OK;
 }

@@ -14,7 +14,15 @@ import torch
 from . import _lib as L
 from .config import SprcConfig
 
-_TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16, L.SPRC_F16: torch.float16}
+_TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16, L.SPRC_F16: torch.float16, L.SPRC_FP8: torch.float8_e4m3fn}
+FP8_MAX = 448.0                                   # largest finite e4m3fn
+
+
+def quantize_fp8_rows(w: torch.Tensor):
+    """Per-output-channel e4m3fn quantisation of a weight [N, K]: W[n, :] = scale[n] * Wq[n, :]."""
+    w = w.float()
+    scale = (w.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX).contiguous()
+    return (w / scale[:, None]).to(torch.float8_e4m3fn).contiguous(), scale
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -33,9 +41,10 @@ def rowmap(rows_per_group: int = 0, group_stride: int = 0, group_offset: int = 0
 # thin operator wrappers (used by the unit parity tests and by Engine)
 # --------------------------------------------------------------------------------------------
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None, act=L.ACT_NONE, out=None,
-         M=None, amap=None, cmap=None, ldc=None, scratch=None) -> torch.Tensor:
+         M=None, amap=None, cmap=None, ldc=None, scratch=None, w_scale=None, a_scale=0.0, out_scale=0.0) -> torch.Tensor:
+    """fp8 operands (torch.float8_e4m3fn A and W): w_scale [N] fp32, a_scale; out_dtype SPRC_FP8 also needs out_scale."""
     lib = L.load()
-    dt = L.SPRC_BF16 if A.dtype == torch.bfloat16 else L.SPRC_F32
+    dt = L.SPRC_BF16 if A.dtype == torch.bfloat16 else L.SPRC_FP8 if A.dtype == torch.float8_e4m3fn else L.SPRC_F32
     assert W.dtype == A.dtype and A.is_cuda and A.stride(-1) == 1 and W.stride(-1) == 1
     N, K = W.shape
     M = A.shape[0] if M is None else M
@@ -51,6 +60,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None
     g.C, g.ldc, g.cmap = out.data_ptr(), (out.stride(0) if ldc is None else ldc), cmap or rowmap()
     if scratch is not None:                      # optional split-K scratch (include/sprc.h)
         g.scratch, g.scratch_bytes = scratch.data_ptr(), scratch.numel() * scratch.element_size()
+    g.w_scale, g.a_scale, g.out_scale = _ptr(w_scale), a_scale, out_scale
     L.check(lib.sprc_gemm(C.byref(g), _stream()), "sprc_gemm")
     return out
 
@@ -166,12 +176,20 @@ class Engine:
     """Packed weights + workspaces for one model on one GPU."""
 
     def __init__(self, cfg: SprcConfig, state_dict: Dict[str, torch.Tensor], device, dtype: str = "bf16",
-                 max_batch: int = 128):
+                 max_batch: int = 128, fp8_amax: Optional[torch.Tensor] = None, fp8_margin: float = 1.0):
+        """dtype "fp8": a bf16 engine whose ViT qkv / fc1 / fc2 GEMMs run on e4m3fn operands (BASELINE.json config C5).
+        fp8_amax [depth, 3]: max |x| of those GEMMs' inputs from `calibrate_fp8` on representative images (static
+        per-tensor activation scales = amax * fp8_margin / 448); weights get per-output-channel scales."""
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise L.SprcError("sprc_amd.Engine needs a GPU device: the HIP kernels are the only compute path")
+        self.fp8 = dtype == "fp8"
+        if self.fp8:
+            if fp8_amax is None or tuple(fp8_amax.shape) != (cfg.vit.depth, 3):
+                raise ValueError(f"the fp8 engine needs fp8_amax [{cfg.vit.depth}, 3] from Engine.calibrate_fp8")
+            self._act_scale = (fp8_amax.detach().float().cpu().clamp_min(1e-6) * fp8_margin / FP8_MAX).tolist()
         self.dt = L.DTYPES[dtype]
         self.tdt = _TORCH_DT[self.dt]
         self.max_batch = max_batch
@@ -197,6 +215,12 @@ class Engine:
     def _lin(self, w: torch.Tensor, b: Optional[torch.Tensor], k_pad: Optional[int] = None) -> L.Linear:
         return L.Linear(self._w(w, k_pad).data_ptr(), None if b is None else self._f32(b).data_ptr())
 
+    def _lin8(self, w: torch.Tensor, b: Optional[torch.Tensor]):
+        """-> (Linear with e4m3fn weights, device pointer of the per-output-channel scales)"""
+        wq, scale = quantize_fp8_rows(w.detach().to(self.device))
+        self._keep += [wq, scale]
+        return L.Linear(wq.data_ptr(), None if b is None else self._f32(b).data_ptr()), scale.data_ptr()
+
     def _pack_vit(self, sd):
         v = self.cfg.vit
         p = "visual_encoder."
@@ -211,16 +235,22 @@ class Engine:
                 qkv_b = torch.cat([sd[b + "attn.q_bias"].float(), torch.zeros_like(sd[b + "attn.v_bias"]).float(),
                                    sd[b + "attn.v_bias"].float()])               # eva_vit.py:120-122
                 names = ("norm1", "norm2", "attn.qkv.weight", "attn.proj", "mlp.fc1", "mlp.fc2")
-                ly.qkv = self._lin(sd[b + names[2]], qkv_b)
             else:
                 b = f"{p}transformer.resblocks.{i}."
                 names = ("ln_1", "ln_2", "attn.in_proj_weight", "attn.out_proj", "mlp.c_fc", "mlp.c_proj")
-                ly.qkv = self._lin(sd[b + names[2]], sd[b + "attn.in_proj_bias"])
+                qkv_b = sd[b + "attn.in_proj_bias"]
+            if self.fp8:
+                ly.qkv, ly.qkv_ws = self._lin8(sd[b + names[2]], qkv_b)
+                ly.fc1, ly.fc1_ws = self._lin8(sd[b + names[4] + ".weight"], sd[b + names[4] + ".bias"])
+                ly.fc2, ly.fc2_ws = self._lin8(sd[b + names[5] + ".weight"], sd[b + names[5] + ".bias"])
+                ly.s_ln1, ly.s_ln2, ly.s_mlp = self._act_scale[i]
+            else:
+                ly.qkv = self._lin(sd[b + names[2]], qkv_b)
+                ly.fc1 = self._lin(sd[b + names[4] + ".weight"], sd[b + names[4] + ".bias"])
+                ly.fc2 = self._lin(sd[b + names[5] + ".weight"], sd[b + names[5] + ".bias"])
             ly.ln1_w, ly.ln1_b = self._f32(sd[b + names[0] + ".weight"]).data_ptr(), self._f32(sd[b + names[0] + ".bias"]).data_ptr()
             ly.ln2_w, ly.ln2_b = self._f32(sd[b + names[1] + ".weight"]).data_ptr(), self._f32(sd[b + names[1] + ".bias"]).data_ptr()
             ly.proj = self._lin(sd[b + names[3] + ".weight"], sd[b + names[3] + ".bias"])
-            ly.fc1 = self._lin(sd[b + names[4] + ".weight"], sd[b + names[4] + ".bias"])
-            ly.fc2 = self._lin(sd[b + names[5] + ".weight"], sd[b + names[5] + ".bias"])
         m = L.VitModel()
         m.dtype, m.width, m.depth, m.heads, m.head_dim, m.mlp = self.dt, D, v.depth, v.heads, v.head_dim, v.mlp
         m.act = L.ACT_GELU if v.act == "gelu" else L.ACT_QUICKGELU
@@ -239,6 +269,7 @@ class Engine:
         m.ln_vision_w = self._f32(sd["ln_vision.weight"]).data_ptr()
         m.ln_vision_b = self._f32(sd["ln_vision.bias"]).data_ptr()
         m.layers = C.cast(layers, C.POINTER(L.VitLayer))
+        m.fp8 = int(self.fp8)
         self._vit_layers, self.vit = layers, m
 
     def _pack_qformer(self, sd):
@@ -289,6 +320,21 @@ class Engine:
         self.itm_b = self._f32(sd["itm_head.bias"]) if "itm_head.bias" in sd else None
         m.layers = C.cast(layers, C.POINTER(L.QfLayer))
         self._qf_layers, self.qf = layers, m
+
+    # ---- fp8 calibration ---------------------------------------------------------------------
+    def calibrate_fp8(self, images: torch.Tensor) -> torch.Tensor:
+        """amax[depth, 3] = max |x| of the inputs of the qkv / fc1 / fc2 GEMMs of every block over `images`, collected by
+        sprc_vit_forward on THIS (bf16) engine; feed it to Engine(..., dtype="fp8", fp8_amax=...)."""
+        if self.dt != L.SPRC_BF16 or self.fp8:
+            raise L.SprcError("calibrate_fp8 runs on a bf16 engine")
+        amax = torch.zeros((self.cfg.vit.depth, 3), dtype=torch.float32, device=self.device)
+        self.vit.calib_amax = amax.data_ptr()
+        try:
+            self.vit_forward(images)
+            torch.cuda.synchronize(self.device)
+        finally:
+            self.vit.calib_amax = None
+        return amax.cpu()
 
     # ---- workspaces ------------------------------------------------------------------------
     def _workspace(self, kind: str, B: int) -> torch.Tensor:
