@@ -173,6 +173,8 @@ typedef struct {
     const float* word_emb; const float* pos_emb;
     const float* gamma; const float* beta; float eps;
     float* y32; void* y16;                      /* [B, Lq+Lt, hidden] contiguous */
+    int32_t no_img;                             /* 1: the text-only form of Qformer.py:88-104 (training, align_prompt.py:173-179): rows =
+                                                 * [text[0] ; the Lq query rows ; text[1:]] and every row gets its absolute position */
 } sprc_qformer_embed_args;
 int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream s);
 
@@ -314,6 +316,31 @@ size_t sprc_preprocess_workspace_bytes(int32_t src_h, int32_t src_w, float targe
 int sprc_preprocess_targetpad(const uint8_t* src, int32_t src_h, int32_t src_w, int64_t src_stride, float target_ratio,
                               int32_t dim, const float* mean, const float* std, float* out,
                               void* ws, size_t ws_bytes, sprc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Training forward: the three losses of Blip2QformerCirAlignPrompt.forward,
+ * lavis/models/blip2_models/blip2_qformer_cir_align_prompt.py:95-200 (eval semantics: dropout = identity).
+ * FORWARD ONLY: no backward kernels; sprc_amd.model.forward returns the losses without autograd history.
+ * ---------------------------------------------------------------------------------------- */
+
+/* sprc_qformer_fuse + loss_align: additionally writes loss_align[0] = mse(mean over the query rows of the PASS-1 output,
+ * mean over the rows of prompt_tokens [num_query, hidden])  (:192-193). */
+int sprc_qformer_fuse_train(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
+                            const int64_t* input_ids, const int64_t* attention_mask, int32_t B,
+                            float* fusion, void* fusion16, const float* prompt_tokens, float* loss_align,
+                            void* ws, size_t ws_bytes, sprc_stream s);
+
+/* feat[B,E] = normalize(text_proj(Qformer(text, query_embeds = prompt_tokens, no_img = True)[:, 0, :]))  (:170-179). */
+int sprc_qformer_text_only(const sprc_qformer_model* m, const float* prompt_tokens, const int64_t* input_ids,
+                           const int64_t* attention_mask, int32_t B, float* feat, void* feat16,
+                           void* ws, size_t ws_bytes, sprc_stream s);
+
+/* loss[0] = F.cross_entropy(sim[B,B] / temp, arange(B))  (:157-167, :181-190);  sim fp32, ld in elements. */
+int sprc_contrastive_ce(const float* sim, int64_t ld, int32_t B, float temp, float* loss, sprc_stream s);
+
+/* loss[0] = mse(mean_j h[b, j, :], mean_j prompt[j, :]), j < Lq; h fp32 with `sample_stride` elements between samples. */
+int sprc_align_mse(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* prompt, int32_t B, float* loss,
+                   sprc_stream s);
 
 #ifdef __cplusplus
 }

@@ -14,6 +14,7 @@ Files written:
   tests/golden/full_clip.npz   full depth ViT-L (23 blocks), 2 images, 3 queries   (--full)
   tests/golden/planted_eva.npz planted-structure weights (scores spread > 1.0), depth-4 ViT-g, 160 gallery x 72 queries:
                                scores, planned targets, the reference's own metrics / submission dicts on them
+  tests/golden/train_eva.npz   training forward: the reference's three losses (loss_itc, loss_rtc, loss_align) on 5 triplets
   tests/golden/rerank_eva.npz  stage-2 rerank: the reference's Blip2QformerCirRerank.inference_rerank on 3 queries x 4 candidates
   tests/golden/metrics.json    reference compute_cirr_val_metrics / compute_fiq_val_metrics /
                                generate_cirr_test_dicts on synthetic sims (with engineered ties)
@@ -305,6 +306,24 @@ def rerank_goldens(out: Path, seed: int = 2):
     print(f"wrote {out}: prob {prob.numpy().round(4).tolist()}")
 
 
+def train_goldens(out: Path, seed: int = 4):
+    """Training forward (N4): the REFERENCE's Blip2QformerCirAlignPrompt.forward (align_prompt.py:95-200) in eval mode on 5
+    (reference, target, caption) triplets, depth-2 ViT-g + the full Q-Former: the three losses."""
+    cfg = get_config("pretrain", vit_depth=2)
+    sd = synth.make_state_dict(cfg, seed=seed)
+    model = ref_import.build_reference_model(cfg, sd)
+    B = 5
+    images = synth.make_images(2 * B, seed=seed)
+    ids, mask, _ = synth.make_queries(B, B, seed=seed + 1)
+    model.tokenizer.set_next(ids, mask)
+    with torch.no_grad():
+        out_d = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
+    np.savez_compressed(out, model_type="pretrain", vit_depth=2, seed=seed, batch=B, image_probe=_np(images[:, :, 0, :4]),
+                        input_ids=ids.numpy(), attention_mask=mask.numpy(),
+                        **{k: np.float64(v.item()) for k, v in out_d.items()})
+    print(f"wrote {out}:", {k: round(v.item(), 6) for k, v in out_d.items()})
+
+
 def caption_goldens(out: Path):
     import importlib
     import types
@@ -360,6 +379,8 @@ def main():
         model_goldens("pretrain", 2, n_img=4, n_q=6, out=GOLD / "tiny_eva.npz")
     if want("tiny_clip"):
         model_goldens("pretrain_vitL", 2, n_img=3, n_q=4, out=GOLD / "tiny_clip.npz")
+    if want("train"):
+        train_goldens(GOLD / "train_eva.npz")
     if want("rerank"):
         rerank_goldens(GOLD / "rerank_eva.npz")
     if want("planted"):

@@ -252,6 +252,48 @@ def inference(sd: SD, cfg, reference_embeds: Tensor, target_feats: Tensor, input
     return similarity(fusion, target_feats)
 
 
+def qformer_text_only(sd: SD, cfg, prompt_embeds: Tensor, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
+    """`BertModel.forward(..., no_img=True)` (Qformer.py:88-104, used by align_prompt.py:173-179): the embedding rows are
+    [text[0] ([CLS]) ; the 32 prompt rows ; text[1:]], EVERY row gets its absolute position (0..63), one LayerNorm; no
+    encoder states -> no cross-attention, text FFN on all rows.  attention_mask [B,64] is used as given."""
+    qc = cfg.qformer
+    p = "Qformer.bert."
+    we = sd[p + "embeddings.word_embeddings.weight"].float()[input_ids]                       # [B,32,H]
+    emb = torch.cat([we[:, :1, :], prompt_embeds.float(), we[:, 1:, :]], dim=1)
+    emb = emb + sd[p + "embeddings.position_embeddings.weight"].float()[:emb.shape[1]].unsqueeze(0)
+    x = _ln(emb, sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], qc.ln_eps)
+    add_mask = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
+    for l in range(qc.layers):
+        b = f"{p}encoder.layer.{l}."
+        a = _bert_attention(sd, b + "attention.", x, x, add_mask, qc.heads, qc.ln_eps)
+        x = _bert_ffn(sd, b + "intermediate.", b + "output.", a, qc.ln_eps)
+    return x
+
+
+def training_losses(sd: SD, cfg, image: Tensor, target: Tensor, input_ids: Tensor, attention_mask: Tensor) -> Dict[str, Tensor]:
+    """`Blip2QformerCirAlignPrompt.forward` align_prompt.py:95-200 in eval mode (dropout = identity), pre-tokenised text:
+    loss_itc (fusion -> target contrastive), loss_rtc (text-only prompt -> target contrastive), loss_align (MSE between
+    the mean fused query token and the mean prompt token)."""
+    B = image.shape[0]
+    Lq = cfg.qformer.num_query
+    temp = sd["temp"].float() if "temp" in sd else torch.tensor(0.07)
+    raw = encode_image_tokens(sd, cfg, image)
+    qt = sd["query_tokens"].float().expand(B, -1, -1)
+    mask = torch.cat([torch.ones((B, Lq), dtype=attention_mask.dtype), attention_mask], dim=1)
+    p1 = qformer_forward(sd, cfg, qt, input_ids, mask, encoder_hidden_states=raw)             # :120-127
+    p2 = qformer_forward(sd, cfg, p1[:, :Lq, :], input_ids, mask)                             # :129-134
+    fusion = _normalize(F.linear(p2[:, 32, :], sd["text_proj.weight"].float(), sd["text_proj.bias"].float()))
+    target_feats, _ = extract_target_features(sd, cfg, target)                                # :141-155
+    targets = torch.arange(B)
+    loss_itc = F.cross_entropy(similarity(fusion, target_feats) / temp, targets)              # :157-167
+    prompt = sd["prompt_tokens"].float().expand(B, -1, -1)
+    t_only = qformer_text_only(sd, cfg, prompt, input_ids, mask)                              # :170-179
+    t_feat = _normalize(F.linear(t_only[:, 0, :], sd["text_proj.weight"].float(), sd["text_proj.bias"].float()))
+    loss_rtc = F.cross_entropy(similarity(t_feat, target_feats) / temp, targets)              # :181-190
+    loss_align = F.mse_loss(p1[:, :Lq, :].mean(1), prompt.mean(1))                            # :192-193
+    return {"loss_itc": loss_itc, "loss_rtc": loss_rtc, "loss_align": loss_align}
+
+
 def inference_rerank(sd: SD, cfg, reference_embeds: Tensor, target_embeds: Tensor, input_ids: Tensor,
                      attention_mask: Tensor) -> Tensor:
     """`Blip2QformerCirRerank.inference_rerank` blip2_qformer_cir_rerank.py:399-445 with pre-tokenised text (N2).

@@ -46,7 +46,7 @@ class AttentionArgs(C.Structure):
 class QformerEmbedArgs(C.Structure):
     _fields_ = [("B", i32), ("Lq", i32), ("Lt", i32), ("hidden", i32), ("out_dtype", i32), ("vocab", i32),
                 ("query_embeds", vp), ("q_bstride", i64), ("input_ids", vp), ("word_emb", vp), ("pos_emb", vp),
-                ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("y16", vp)]
+                ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("y16", vp), ("no_img", i32)]
 
 
 class ProfEntry(C.Structure):
@@ -120,6 +120,10 @@ SIGNATURES = {
     "sprc_qformer_itm_workspace_bytes": (sz, [C.POINTER(QformerModel), i32]),
     "sprc_qformer_itm": (i32, [C.POINTER(QformerModel), vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, sz, vp]),
     "sprc_itm_head": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, vp]),
+    "sprc_qformer_fuse_train": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "sprc_qformer_text_only": (i32, [C.POINTER(QformerModel), vp, vp, vp, i32, vp, vp, vp, sz, vp]),
+    "sprc_contrastive_ce": (i32, [vp, i64, i32, f32, vp, vp]),
+    "sprc_align_mse": (i32, [vp, i64, i32, i32, vp, i32, vp, vp]),
     "sprc_preprocess_workspace_bytes": (sz, [i32, i32, f32, i32]),
     "sprc_preprocess_targetpad": (i32, [vp, i32, i32, i64, f32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, sz, vp]),
 }

@@ -565,10 +565,13 @@ static int launch_bf16(const AttnParams& p, hipStream_t st) {
         return SPRC_EUNSUPPORTED;
     }
     auto kern = attn_bf16_kernel<DHP, NW>;
-    static size_t attr = 0;
-    if (lds > attr) {
+    static size_t attr[64] = {0};               // hipFuncSetAttribute applies to the current device: one high-water mark per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev >= 0 && dev < 64 ? dev : 0;
+    if (lds > attr[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = lds;
+        attr[dev] = lds;
     }
     hipLaunchKernelGGL(kern, dim3(p.B * p.H), dim3(64 * NW), lds, st, p);
     SPRC_CHECK_LAUNCH("sprc_attention(bf16)");

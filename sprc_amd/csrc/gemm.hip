@@ -1,932 +1,9 @@
-// gemm.hip -- C = epilogue(A[M,K] . W[N,K]^T) on gfx950 matrix cores.
-//
-// Replaces every nn.Linear / F.linear / conv-as-GEMM on the SPRC retrieval path (see sprc.h).
-// Both operands are K-contiguous ("B^T" form), so A and W fragments are read the same way.
-//
-// Two kernels (workgroup tile BM x BN, K-tile = 128 bytes of K):
-//   gemm_anti_kernel  256 x 256, 8 waves (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA 32x32 accumulators, 1 WG / CU, bf16:
-//                     two wave groups in anti-phase (one in a 16-MFMA cluster while the other reads fragments and
-//                     stages), piece-scheduled staging with counted vmcnt -- see the comment above the kernel
-//   gemm_kernel       128 x 128, 4 waves (2 x 2), wave tile 64 x 64, 2 WGs / CU (small grids, remainder rows, split-K,
-//                     and every fp32 GEMM; also instantiated as a lock-step 256 x 256 for the fp32 engine)
-//     bf16: v_mfma_f32_32x32x16_bf16, K-tile = 64 elements;  f32: v_mfma_f32_32x32x2_f32 (exact fp32), 32 elements
-// The dispatcher (launch<>) chooses between them -- and a "256x256 on the first M & ~255 rows + 128x128 on the rest"
-// split -- with a round-count cost model.
-// Data movement: K-tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds through an SRSRC based at the tile's
-// first row: 1 KiB per wave-instruction, no VGPR round trip, no per-load address arithmetic), double buffered.  The LDS
-// image of a wave-instruction is lane-linear (8 rows x 8 16-B slots), so the XOR swizzle (slot ^= (row>>1)&7: every
-// ds_read_b128 lane group hits 16 distinct slots of the 256-B bank row, SQ_LDS_BANK_CONFLICT = 0) is applied to the
-// per-lane SOURCE offset and to the fragment reads, never to the destination (guide rule 21).
-// The 128x128 bf16 main loop is hand software-pipelined (inline-asm ds_read_b128 + counted lgkmcnt): fragment reads of
-// k-step kk+1 and a quarter of the next K-tile's loads are issued before the MFMAs of k-step kk.
-// Tile order: XCD-contiguous remap of the block index (block b runs on XCD b%8) + grouped order, so tiles resident on
-// one XCD share A/W panels in its L2.
-// Epilogue: MFMAs compute the TRANSPOSED tile, so a lane owns one C row and 4 consecutive columns per register
-// quad: bias / residual / output are 16-B (fp32) or 8-B (bf16) vectors.
-#include <stdlib.h>
-
-#include <type_traits>
-
-#include "common.hpp"
+// gemm.hip -- C entry points of the GEMM (sprc_gemm, sprc_gemm_pair, sprc_sim_max) and the bf16-operand instantiations.
+// Kernels and launchers: gemm_impl.hpp.
+#include "gemm_impl.hpp"
 
 namespace sprc {
-
-struct GemmParams {
-    int M, N, K;
-    const char* A; int64_t lda_b;       // leading dims in BYTES
-    const char* W; int64_t ldw_b;
-    const float* bias;
-    const float* resid; int64_t ldr;
-    void* C; int64_t ldc;
-    int a_shift, a_stride, a_off;       // row maps (rows_per_group = 1<<shift, shift<0 -> identity)
-    int c_shift, c_stride, c_off;
-    int tiles_m, tiles_n;
-    float* scratch; int64_t scratch_elems;   // optional caller scratch (split-K partials)
-    int order;                          // tile order (tile_origin): 0 = 8-m grouped, n > 0 = groups of n n-tiles sweeping m
-    int dual;                           // 1: the grid holds TWO products of identical shape; workgroups >= nwg0 take the second set
-    int nwg0;
-    const char* W2; const float* bias2; int a_off2, c_off2;      // what differs in the second product: weight, bias, row-map offsets
-    int ksplit;                         // > 1: split-K launch of the 128x128 kernel (grid = tiles x ksplit), raw fp32 partials
-    int64_t split_stride;               // elements between the partial planes of consecutive K splits
-    const float* w_scale; float a_scale;     // fp8 operands: acc * (a_scale * w_scale[n]) before the bias (null: no scaling)
-    float out_scale;                    // fp8 output: value * out_scale before the conversion (1 / the consumer's dequantisation scale)
-    int debug;                          // SPRC_GEMM_DEBUG, timing experiments on the 256x256 kernel (results are WRONG with 1 / 2):
-                                        //   1 no global->LDS loads   2 no fragment reads   64 s_memtime stamp build (tools/gemm_stamp.py)
-                                        //   512 all four loads of an interval pair in the NC interval   1024 no residual prefetch
-};
-
-__device__ __forceinline__ int64_t map_row_s(int shift, int stride, int off, int r) {
-    if (shift < 0) return r;
-    return (int64_t)(r >> shift) * stride + (r & ((1 << shift) - 1)) + off;
-}
-
-// GELU of the bf16 epilogue: x * Phi(x) with Phi(x) ~ 1 / (1 + 2^(x (k0 + k1 t + k2 t^2))), t = min(x^2, 80) -- a logistic
-// approximation of the normal CDF with a fitted odd quintic exponent: |gelu error| <= 2.6e-5 for every finite x (checked
-// in fp32 on [-40, 40]), an order below the bf16 rounding of the stored value.  9 VALU ops per value.  The epilogue runs
-// with the matrix pipe idle and is VALU-issue bound (4 cycles per wave64 op, two waves per SIMD), so it costs what it
-// counts: on the 750-us ViT fc1 GEMM the erf form (A&S 7.1.26, ~17 ops) took 150 us, a degree-8 Horner polynomial (13 ops,
-// packed or scalar, pinned constants or literals -- all the same) 106-117 us, x*sigmoid(1.702x) (5 ops) 40 us.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float t = fminf(x * x, 80.0f);
-    float q = fmaf(t, 1.014263136e-03f, -1.067757234e-01f);
-    q = fmaf(q, t, -2.301121235e+00f);
-    const float e = __builtin_amdgcn_exp2f(x * q);          // +inf for very negative x: rcp(inf) = 0
-    return x * __builtin_amdgcn_rcpf(e + 1.0f);
-}
-
-typedef _Float16 f16_t;
-struct fp8_t { uint8_t bits; };        // OCP e4m3fn (gfx950), operand / output tag type
-
-// saturating fp32 -> 2 x e4m3fn (v_cvt_pk_fp8_f32: RNE; inputs clamped to +-448 first, the format has no infinity)
-__device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, bool hi) {
-    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f);
-    b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
-    return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
-}
-// 4 consecutive outputs of one row: 16 B (fp32) or 8 B (bf16 / fp16)
-template <typename OutT>
-__device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v) {
-    if constexpr (std::is_same<OutT, float>::value) {
-        *reinterpret_cast<f32x4*>(dst) = v;
-    } else if constexpr (std::is_same<OutT, f16_t>::value) {
-        typedef __attribute__((ext_vector_type(4))) _Float16 half4;
-        *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-    } else if constexpr (std::is_same<OutT, fp8_t>::value) {
-        *reinterpret_cast<uint32_t*>(dst) = pack_fp8x2(v[2], v[3], pack_fp8x2(v[0], v[1], 0u, false), true);
-    } else {
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-        *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    }
-}
-
-// one output element (the ragged-N scalar path)
-template <typename OutT>
-__device__ __forceinline__ void store_out1(OutT* dst, float v) {
-    if constexpr (std::is_same<OutT, fp8_t>::value) dst->bits = (uint8_t)(pack_fp8x2(v, 0.f, 0u, false) & 0xffu);
-    else *dst = (OutT)v;
-}
-
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> { typedef bf16x8 type; };
-template <> struct Frag<float> { typedef f32x4 type; };
-template <> struct Frag<fp8_t> { typedef u32x4 type; };       // unused: the fp8 main loop is the hand-pipelined one
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Raw-buffer (SRSRC) 16-B-per-lane load straight into LDS.  Kept in NON-template helpers: this hipcc silently drops the
-// host stub of a kernel TEMPLATE whose dependent code calls the buffer builtins directly.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xffffffff, 0x00020000);
-}
-__device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t voffset, int soffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds_dst, 16, voffset, soffset, 0, 0);
-}
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// ds_read_b128 the compiler cannot sink: issued where written, completion tracked by OUR lgkmcnt (guide 5.7).
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkmcnt() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);       // keep the MFMAs below the wait (guide rule 18)
-}
-
-// One K-tile (4 MFMA k-steps) of a wave's TM x TN accumulator block, hand software-pipelined.
-// a_base / b_base: LDS byte address of this lane's first A / W row in the current stage; c0 = swizzled slot of
-// k-step 0 ((half ^ f(row)) << 4); k-step kk reads slot c0 ^ (kk << 5).
-// fp8 (FP8 = true): a 16-B fragment holds 16 k-values = TWO e4m3 MFMA k-steps (low / high 8 bytes); which bytes form a
-// k-step is a free permutation of k as long as both operands use the same one, so the LDS layout and the reads are the bf16 ones.
-__device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x16 c, std::false_type) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x16 c, std::true_type) {
-    const long b0 = (long)(((uint64_t)b[1] << 32) | b[0]), b1 = (long)(((uint64_t)b[3] << 32) | b[2]);
-    const long a0 = (long)(((uint64_t)a[1] << 32) | a[0]), a1 = (long)(((uint64_t)a[3] << 32) | a[2]);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b0, a0, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b1, a1, c, 0, 0, 0);
-}
-
-template <int TM, int TN, int KT_BYTES, bool FP8, typename Issue>
-__device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base, uint32_t c0, f32x16 (&acc)[TM][TN],
-                                                Issue&& issue) {
-    static_assert(KT_BYTES == 128, "4 k-steps per K-tile");
-    u32x4 fa[2][TM], fb[2][TN];
-    {
-        const uint32_t an = a_base + c0, bn = b_base + c0;
-        static_for<0, TM>([&](auto i) { fa[0][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(an); });
-        static_for<0, TN>([&](auto i) { fb[0][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(bn); });
-    }
-    static_for<0, 4>([&](auto kk_) {
-        constexpr int kk = decltype(kk_)::value, cur = kk & 1, nxt = cur ^ 1;
-        if constexpr (kk < 3) {
-            const uint32_t cn = c0 ^ ((kk + 1) << 5), an = a_base + cn, bn = b_base + cn;
-            static_for<0, TM>([&](auto i) { fa[nxt][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(an); });
-            static_for<0, TN>([&](auto i) { fb[nxt][i] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(bn); });
-        }
-        issue(kk_);
-        if constexpr (kk < 3) wait_lgkmcnt<TM + TN>();
-        else wait_lgkmcnt<0>();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = mfma_frag(fb[cur][ni], fa[cur][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
-        __builtin_amdgcn_s_setprio(0);
-    });
-}
-
-// Tile order.  Block b runs on XCD b%8 (observed dispatch); the remap gives every XCD a CONTIGUOUS range of `pid`s, and
-// the pid -> (m,n) map walks a group of GN n-tiles over ALL m-tiles (m fastest inside the group).  The ~32 workgroups
-// resident on one XCD then form an 8(m) x 4(n) patch (12 operand panels per 32 tiles), and successive rounds on that XCD
-// keep the SAME 4 W panels (2.9 MB, L2-resident) while the A panels stream through once.  (mode 0: the earlier
-// 8-m-tile grouped order, where both operands change every round.)
-__device__ __forceinline__ void tile_origin(int vb, int nwg, int tiles_m, int tiles_n, int BM, int BN, int mode, int& m0, int& n0) {
-    const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
-    const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-    if (mode == 0) {
-        constexpr int GROUP_M = 8;
-        const int in_group = GROUP_M * tiles_n;
-        const int first_m = (pid / in_group) * GROUP_M;
-        const int gsz = min(tiles_m - first_m, GROUP_M);
-        m0 = (first_m + (pid % in_group) % gsz) * BM;
-        n0 = ((pid % in_group) / gsz) * BN;
-    } else {
-        const int GN = mode;                      // n-tiles per group
-        const int in_group = GN * tiles_m;
-        const int first_n = (pid / in_group) * GN;
-        const int gsz = min(tiles_n - first_n, GN);
-        const int rem = pid % in_group;
-        // inside a group: blocks of 8 m-tiles x gsz n-tiles, m fastest
-        const int blk = rem / (8 * gsz), inb = rem % (8 * gsz);
-        const int mrem = min(tiles_m - blk * 8, 8);
-        m0 = (blk * 8 + inb % mrem) * BM;
-        n0 = (first_n + inb / mrem) * BN;
-    }
-}
-
-// ---- epilogue (shared).  Transposed 32x32 D layout: m = rbase + (lane&31),  n = cbase + 8*(r>>2) + 4*(lane>>5) + (r&3) ----
-// Each wave transposes its accumulators through a private LDS strip (32 rows x (32 TN + 4) floats: the padding makes both
-// the ds_write_b128 of the fragment layout and the row-major ds_read_b128 conflict-free) so that global memory sees FULL
-// cache lines: one wave instruction covers 64/(8 TN) whole rows x 128 TN bytes.  With the fragment layout written straight
-// out, an instruction touched 32 rows x 32 B and a 256 x 256 fp32 tile with residual took ~55k cycles (7 B/clk/CU,
-// store-issue bound: s_memtime, tools/gemm_stamp.py) -- more than a third of a K = 1408 tile.
-// The caller guarantees every wave is done reading operand tiles from LDS (a barrier after the K loop).
-constexpr int EPI_STRIP_BYTES(int TN) { return 32 * (32 * TN + 4) * 4; }
-
-template <typename T, typename OutT, int ACT, bool MAX32, int TM, int TN>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TM][TN], int cm0, int cn0, int wr, int wc,
-                                              int r32, int half, bool vec_ok, char* smem, int wave) {
-    if constexpr (!MAX32) {
-        if (vec_ok) {
-            constexpr int CH = 8 * TN, RPI = 64 / CH, ITERS = 32 / RPI, LD = (32 * TN + 4) * 4;   // 16-B chunks per row, rows per instruction
-            const int lane = half * 32 + r32, ch = lane % CH, rsub = lane / CH;
-            char* strip = smem + wave * EPI_STRIP_BYTES(TN);
-            const int col = cn0 + wc * TN * 32 + ch * 4;
-            const bool col_ok = col < p.N;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-            f32x4 sv = {1.f, 1.f, 1.f, 1.f};               // fp8 operands: per-output-channel dequantisation
-            const bool scaled = p.w_scale != nullptr;
-            if (scaled && col_ok) {
-                sv = *reinterpret_cast<const f32x4*>(p.w_scale + col);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sv[e] *= p.a_scale;
-            }
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                // residual rows of this block first (C may alias it: every element is read by the lane that writes it)
-                f32x4 rv[ITERS];
-                int64_t prow[ITERS];
-                bool ok[ITERS];
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int row = cm0 + (wr * TM + mi) * 32 + it * RPI + rsub;
-                    ok[it] = row < p.M && col_ok;
-                    prow[it] = map_row_s(p.c_shift, p.c_stride, p.c_off, row < p.M ? row : 0);
-                    rv[it] = (p.resid != nullptr && ok[it]) ? *reinterpret_cast<const f32x4*>(p.resid + prow[it] * p.ldr + col)
-                                                           : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<f32x4*>(strip + r32 * LD + (ni * 32 + 8 * g + 4 * half) * 4) =
-                            f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + rsub) * LD + ch * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {           // element-wise on purpose: vector adds become v_pk_add_f32 (slower)
-                        if (scaled) v[e] *= sv[e];
-                        v[e] += bv[e];
-                        if constexpr (ACT == SPRC_ACT_GELU) {
-                            if constexpr (sizeof(T) <= 2) v[e] = gelu_fast(v[e]);
-                            else v[e] = gelu_erf(v[e]);
-                        }
-                        if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
-                        v[e] += rv[it][e];
-                        if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= p.out_scale;
-                    }
-                    if (!ok[it]) continue;
-                    store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + prow[it] * p.ldc + col, v);
-                }
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int row = cm0 + (wr * TM + mi) * 32 + r32;
-        if constexpr (MAX32) {
-            // rows m = query vectors, columns n = gallery tokens: max over the 32 columns of one image
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int cbase = cn0 + (wc * TN + ni) * 32;
-                float v = acc[mi][ni][0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) v = fmaxf(v, acc[mi][ni][r]);
-                v = fmaxf(v, __shfl_xor(v, 32, 64));
-                if (half == 0 && row < p.M && cbase < p.N)
-                    reinterpret_cast<float*>(p.C)[(int64_t)row * p.ldc + (cbase >> 5)] = v;
-            }
-        } else {
-            const bool row_ok = row < p.M;
-            const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, row_ok ? row : 0);
-            const float* rrow = p.resid ? p.resid + prow * p.ldr : nullptr;
-            OutT* crow = reinterpret_cast<OutT*>(p.C) + prow * p.ldc;
-            {                                         // unaligned / ragged N: scalar path (the vector path returned above)
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int col = cn0 + (wc * TN + ni) * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                        if (!(row_ok && col < p.N)) continue;
-                        float v = acc[mi][ni][r];
-                        if (p.w_scale != nullptr) v *= p.a_scale * p.w_scale[col];
-                        v += (p.bias ? p.bias[col] : 0.f);
-                        if constexpr (ACT == SPRC_ACT_GELU) {
-                            if constexpr (sizeof(T) <= 2) v = gelu_fast(v);
-                            else v = gelu_erf(v);
-                        }
-                        if constexpr (ACT == SPRC_ACT_QUICKGELU) v = quick_gelu(v);
-                        if (rrow != nullptr) v += rrow[col];
-                        if constexpr (std::is_same<OutT, fp8_t>::value) v *= p.out_scale;
-                        store_out1<OutT>(crow + col, v);
-                    }
-            }
-        }
-    }
-}
-
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KT_BYTES = 128;
-    constexpr int NT = 64 * WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int STAGE_BYTES = (BM + BN) * KT_BYTES;
-    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;          // 16-B chunks per thread per K-tile
-    constexpr int LQ = (LA + LB) / 4;                          // global->LDS loads issued per MFMA k-step
-    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0 && (LA + LB) % 4 == 0, "tile/threads mismatch");
-    typedef typename Frag<T>::type frag_t;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave / WN, wc = wave % WN;
-    const int r32 = lane & 31, half = lane >> 5;
-    const int nwg = p.tiles_m * p.tiles_n;
-    int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
-    int vb = blockIdx.x, ks = 0;
-    if (p.dual && vb >= p.nwg0) {                               // second product of a paired launch
-        vb -= p.nwg0;
-        p.W = p.W2; p.bias = p.bias2; p.a_off = p.a_off2; p.c_off = p.c_off2;
-    }
-    int64_t kbase = 0;                                          // byte offset of this workgroup's first K-tile
-    if (p.ksplit > 1) {                                         // split-K: workgroup (tile vb, split ks) reduces K-tiles [t0, t0 + nt)
-        ks = vb / nwg;
-        vb -= ks * nwg;
-        const int per = (nt + p.ksplit - 1) / p.ksplit, t0 = min(ks * per, nt);
-        nt = min(per, nt - t0);
-        kbase = (int64_t)t0 * KT_BYTES;
-    }
-
-    // ---- direct-to-LDS staging: lane fills physical slot (chunk&7) of row (chunk>>3) with logical slot^f(row) ----
-    // SRSRC buffer loads (workgroup-uniform base = first row of the tile, 32-bit lane offsets, K-tile offset in an SGPR):
-    // no per-load address VALU, and they issue 2-3x faster than global_load_lds with 64-bit lane addresses.
-    int m0, n0;
-    tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
-    const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
-    const char* a_base = p.A + a_row0 * p.lda_b;            // resources are rebuilt from these at each use (loop-invariant SGPRs)
-    const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
-    uint32_t a_src[LA], w_src[LB];
-#pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
-        const int am = min(m0 + row, p.M - 1);
-        a_src[i] = (uint32_t)((map_row_s(p.a_shift, p.a_stride, p.a_off, am) - a_row0) * p.lda_b) + slot * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < LB; ++i) {
-        const int c = i * NT + tid, row = c >> 3, slot = (c & 7) ^ ((row >> 1) & 7);
-        w_src[i] = (uint32_t)((int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldw_b) + slot * 16;
-    }
-    auto stage_one = [&](auto j_, char* dst, int64_t ko) {      // j-th of the LA+LB loads of one K-tile
-        constexpr int j = decltype(j_)::value;
-        if constexpr (j < LA)
-            buffer_load_lds16(make_rsrc(a_base), dst + j * NT * 16, a_src[j], (int)ko);
-        else
-            buffer_load_lds16(make_rsrc(w_base), dst + BM * KT_BYTES + (j - LA) * NT * 16, w_src[j - LA], (int)ko);
-    };
-
-    const int sw = (r32 >> 1) & 7;
-    const int a_off = (wr * TM * 32 + r32) * KT_BYTES, b_off = BM * KT_BYTES + (wc * TN * 32 + r32) * KT_BYTES;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-    const uint32_t c0 = (uint32_t)((half ^ sw) << 4);
-    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
-                        ((uintptr_t)p.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)p.bias % 16 == 0) && ((uintptr_t)p.resid % 16 == 0);
-
-    if (nt > 0) {                                               // K-tile 0
-        char* dst0 = smem + wave * 1024;
-        static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst0, kbase); });
-    }
-
-    {
-        f32x16 acc[TM][TN];
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-        // ---- main loop: K-tile t is in buffer t&1 (tile 0 was issued before we got here) ----
-        for (int t = 0; t < nt; ++t) {
-            __syncthreads();                 // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free again
-            const bool more = t + 1 < nt;
-            const int64_t ko = kbase + (int64_t)(t + 1) * KT_BYTES;
-            if constexpr (sizeof(T) <= 2) {
-                char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
-                const uint32_t so = lds0 + (t & 1) * STAGE_BYTES;
-                pipe_ktile_bf16<TM, TN, KT_BYTES, sizeof(T) == 1>(so + a_off, so + b_off, c0, acc, [&](auto kk_) {
-                    constexpr int kk = decltype(kk_)::value;
-                    if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
-                });
-            } else {
-                if (more) {
-                    char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
-                    static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst, ko); });
-                }
-                const char* st = smem + (t & 1) * STAGE_BYTES;
-                frag_t fa[2][TM], fb[2][TN];
-                auto load = [&](int buf, int kk) {
-                    const int slot = ((kk * 2 + half) ^ sw) << 4;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[buf][i] = *reinterpret_cast<const frag_t*>(st + a_off + i * 32 * KT_BYTES + slot);
-#pragma unroll
-                    for (int i = 0; i < TN; ++i) fb[buf][i] = *reinterpret_cast<const frag_t*>(st + b_off + i * 32 * KT_BYTES + slot);
-                };
-                load(0, 0);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (kk + 1 < 4) load((kk + 1) & 1, kk + 1);
-                    // each lane holds 4 consecutive k of its half; MFMA step e pairs k = {8kk+e, 8kk+4+e}
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                            for (int ni = 0; ni < TN; ++ni)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[kk & 1][ni][e], fa[kk & 1][mi][e], acc[mi][ni], 0, 0, 0);
-                }
-            }
-        }
-
-        __syncthreads();                     // every wave is done reading operand tiles: the epilogue reuses LDS
-        if (p.ksplit > 1) {
-            GemmParams pe = p;
-            pe.C = reinterpret_cast<OutT*>(p.C) + ks * p.split_stride;
-            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(pe, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
-        } else {
-            gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
-        }
-    }
-}
-
-// out = act(sum_s partial[s] + bias) + resid for the split-K remainder launch (fixed summation order: deterministic)
-template <typename OutT, int ACT>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t stride, int M, int N,
-                                                            const float* __restrict__ bias, const float* resid, int64_t ldr,
-                                                            OutT* C, int64_t ldc, const float* __restrict__ w_scale, float a_scale,
-                                                            float out_scale) {
-    const int n4 = N / 4;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)M * n4) return;
-    const int row = (int)(i / n4), col = (int)(i % n4) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)row * N + col);
-    for (int s = 1; s < S; ++s) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(part + s * stride + (int64_t)row * N + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += w[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (w_scale != nullptr) v[e] *= a_scale * w_scale[col + e];
-        if (bias != nullptr) v[e] += bias[col + e];
-        if constexpr (ACT == SPRC_ACT_GELU) v[e] = gelu_fast(v[e]);
-        if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
-        if (resid != nullptr) v[e] += resid[(int64_t)row * ldr + col + e];
-        if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= out_scale;
-        store_out1<OutT>(C + (int64_t)row * ldc + col + e, v[e]);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Anti-phase bf16 variant of the 256 x 256 tile (the schedule idea of the guide's 8-phase template, T3/T4/T5).
-// PMC on the lock-step kernel: matrix pipe busy 55 %, waves 54 % in issue stalls + 28 % in s_waitcnt/barrier -- the two
-// waves that share a SIMD hit their MFMA clusters at the same time and then sit at the K-tile barrier together.
-// Here the 8 waves form two groups (G0 = waves 0-3, G1 = waves 4-7; wave w and w+4 share a SIMD) that alternate:
-// in every barrier interval ONE group runs a 16-MFMA cluster (half a K-tile: k-steps 2h, 2h+1) while the OTHER reads its
-// next fragments from LDS (12 ds_read_b128) and waits for them.  G1 lags G0 by one interval (one extra s_barrier up
-// front, one fewer at the end), so per K-tile a wave executes  NC(t,0) | C(t,0) | NC(t,1) | C(t,1)  with a raw s_barrier
-// after each, and on every SIMD the matrix pipe always has exactly one producer.
-// Staging (measured with s_memtime, tools/gemm_stamp.py: an NC interval carrying 12 ds_read_b128 + 4 global->LDS loads takes
-// 500-700 cycles to ISSUE against a 560-cycle cluster, and draining to vmcnt(0) costs up to 500 more): the K-tile is cut
-// into eight 8-KB pieces (64 rows x 128 B: A0..A3, B0..B3; group g reads A(2g), A(2g+1) and every B), two loads per thread
-// per piece, TWO pieces per interval pair and group (as SRSRC buffer loads: a global_load_lds with its 64-bit lane
-// addresses took 2-3x longer to issue) -- three loads in the NC interval, the fourth inside the following cluster -- and
-// every wait is a counted vmcnt(3/4) that leaves the newest pieces in flight:
-//   interval     4t-1            4t              4t+1            4t+2            4t+3
-//   issues       G1: A0 A1(t+1)  G0: B0 B1(t+1)  G1: B2 B3(t+1)  G0: A2 A3(t+1)  G1: A0 A1(t+2)
-//   first read of tile t+1: A0 A1 B* in 4t+4 (G0), A2 A3 in 4t+5 (G1); last read of tile t-1: A0 A1 in 4t-2, rest in 4t-1.
-//   RAW  the issuing wave retires a piece (counted vmcnt) before the barrier closing the interval BEFORE its first read:
-//        G0 after C(t,1) (4t+3: B0 B1 of t+1) and after NC(t,0) (4t: A2 A3 of t); G1 after NC(t,1) (4t+3: A0 A1 B2 B3 of
-//        t+1).  Every piece has >= 2 intervals between issue and wait.
-//   WAR  a piece is restaged >= 1 interval after the barrier that followed the last read of the region it overwrites.
-template <typename OutT, int ACT, bool MAX32, bool STAMP = false, bool FP8 = false>
-__global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename std::conditional<FP8, fp8_t, bf16_t>::type T;
-    constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
-    constexpr int BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * KTB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = __builtin_amdgcn_readfirstlane(wave / WN), wc = wave % WN;   // wr doubles as the phase group (SGPR: barriers under it)
-    const int r32 = lane & 31, half = lane >> 5;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int nt = FP8 ? p.K / 128 : p.K / 64;             // K-tiles of 128 bytes
-    uint64_t tile_ts[4] = {0, 0, 0, 0};                      // STAMP build: entry | prologue done | K loop done | epilogue done
-    if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
-
-    int vb = blockIdx.x;
-    if (p.dual && vb >= p.nwg0) {                           // second product of a paired launch
-        vb -= p.nwg0;
-        p.W = p.W2; p.bias = p.bias2; p.a_off = p.a_off2; p.c_off = p.c_off2;
-    }
-    int m0, n0;
-    tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
-    // piece q of this group: q = 0, 1 issued in NC(t,0), q = 2, 3 in NC(t,1):  G0: B0 B1 | A2 A3    G1: B2 B3 | A0 A1
-    // (K-tile t+1, except G1's A0 A1 which already belong to K-tile t+2)
-    const int ltid = tid & 255, wg = wave & 3;
-    const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of the piece in its operand
-    const bool pc_is_a[4] = {false, false, true, true};
-    uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk from the tile's first row (K-tile 0)
-    uint32_t pc_dst[4];                                     // LDS byte offset inside a stage (wave-uniform)
-    __amdgpu_buffer_rsrc_t pc_rsrc[4];                      // raw buffer over A or W: SGPR base + 32-bit offsets, no per-load VALU
-    const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
-    const char* a_base = p.A + a_row0 * p.lda_b;
-    const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = j * 256 + ltid, row = pc_row[q] + (c >> 3);
-            const int slot = (c & 7) ^ ((row >> 1) & 7);
-            const int64_t oa = (map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b;
-            const int64_t ow = (int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldw_b;
-            pc_off[q][j] = (uint32_t)(pc_is_a[q] ? oa : ow) + slot * 16;
-        }
-        pc_dst[q] = ((pc_is_a[q] ? 0 : BM) + pc_row[q]) * KTB + wg * 1024;
-        pc_rsrc[q] = make_rsrc(pc_is_a[q] ? a_base : w_base);
-    }
-    auto load_piece = [&](auto q_, auto j_, int tile) {     // j-th load (of 2) of piece q of K-tile `tile`
-        constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
-        char* dst = smem + (tile & 1) * STAGE_BYTES + pc_dst[q] + j * 4096;
-        buffer_load_lds16(pc_rsrc[q], dst, pc_off[q][j], tile * KTB);
-    };
-    using std::integral_constant;
-    typedef integral_constant<int, 0> I0;
-    typedef integral_constant<int, 1> I1;
-    typedef integral_constant<int, 2> I2;
-    typedef integral_constant<int, 3> I3;
-    auto piece = [&](auto q_, int tile) { load_piece(q_, I0{}, tile); load_piece(q_, I1{}, tile); };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-    const uint32_t c0 = (uint32_t)((half ^ ((r32 >> 1) & 7)) << 4);
-    const uint32_t a_off = lds0 + (wr * TM * 32 + r32) * KTB, b_off = lds0 + BM * KTB + (wc * TN * 32 + r32) * KTB;
-    u32x4 fa[2][TM], fb[2][TN];
-    auto reads = [&](int t, int h) {                        // fragments of K-tile t, k-steps 2h and 2h+1
-        const uint32_t so = (t & 1) * STAGE_BYTES;
-        static_for<0, 2>([&](auto k_) {
-            constexpr int k = decltype(k_)::value;
-            const uint32_t cn = c0 ^ ((2 * h + k) << 5), an = a_off + so + cn, bn = b_off + so + cn;
-            static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(an); });
-            static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(bn); });
-        });
-    };
-    // 16 MFMAs: k-steps 2h, 2h+1 of the 128 x 64 wave tile; when `tile` >= 0 the SECOND load of piece q goes out mid-cluster
-    auto cluster = [&](auto q_, int tile) {
-        __builtin_amdgcn_s_setprio(1);
-        static_for<0, 16>([&](auto x_) {
-            constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
-            acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
-            if constexpr (x == 7) { if (tile >= 0) load_piece(q_, I1{}, tile); }
-        });
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto wait_vm = [&](bool newer) {                        // leave the newest two pieces (4 loads) in flight, if issued
-        if (newer) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-    };
-    auto barrier = [&]() {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-
-    // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
-    // flight, G1 one interval behind
-    static_for<0, 4>([&](auto q_) { piece(q_, 0); });
-    if (wr == 1 && nt > 1) { piece(I2{}, 1); piece(I3{}, 1); wait_vmcnt<4>(); }
-    else wait_vmcnt<0>();
-    barrier();
-    if (wr == 1) barrier();
-    if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
-    const bool dbg_noload = p.debug & 1, dbg_noread = p.debug & 2;
-    // 3 of an interval pair's 4 loads go out in the NC interval, the 4th after the 8th MFMA of the following cluster:
-    // NC (12 fragment reads + loads, ~600 cycles) was longer than the cluster (~530); A/B +2 % (debug bit 512 = all 4 in NC)
-    const bool split31 = !(p.debug & 512);
-    if (dbg_noread) { reads(0, 0); wait_lgkmcnt<0>(); }
-    // STAMP build (tools only): s_memtime at the phase boundaries of K-tile 8, written over p.resid by waves 0 and 4 of WG 0
-    uint64_t ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto stamp = [&](auto i_, int t) {
-        if constexpr (STAMP) {
-            if (t == 8 && ((p.ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
-        }
-    };
-    // Residual prefetch: one throw-away dword load per 128-B line of this wave's 128 x 64 fp32 residual block (4 per lane),
-    // issued in the LAST K-tile -- no staging load is outstanding or issued any more, so its vmcnt waits are dropped --
-    // so that the read half of the epilogue's HBM burst happens under the last MFMAs and the epilogue finds the lines in L2.
-    const bool pf_resid = p.resid != nullptr && !(p.debug & 1024);
-    const float* pf_addr[4];
-    uint32_t pf_sink = 0;
-    if (pf_resid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int line = i * 64 + lane, row = m0 + wr * 128 + (line >> 1), col = n0 + wc * 64 + (line & 1) * 32;
-            const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, min(row, p.M - 1));
-            pf_addr[i] = p.resid + prow * p.ldr + min(col, p.N - 1);
-        }
-    }
-    for (int t = 0; t < nt; ++t) {
-        const bool n1 = t + 1 < nt && !dbg_noload, n2 = t + 2 < nt && !dbg_noload;
-        const bool last = t + 1 == nt;
-        const int t_p2 = wr ? t + 2 : t + 1;                // K-tile of the pieces issued in NC(t,1)
-        const bool has_p2 = wr ? n2 : n1;
-        stamp(integral_constant<int, 0>{}, t);
-        if (!dbg_noread) reads(t, 0);                       // NC(t,0)
-        if (n1) { piece(I0{}, t + 1); load_piece(I1{}, I0{}, t + 1); if (!split31) load_piece(I1{}, I1{}, t + 1); }
-        stamp(integral_constant<int, 1>{}, t);
-        wait_lgkmcnt<0>();
-        if (wr == 0) {                                      // A2 A3 of t landed (G1 reads them in the next interval)
-            if (split31 && n1) wait_vmcnt<3>(); else wait_vm(n1);
-        }
-        if (last && pf_resid) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_addr[i]) : "memory");
-        }
-        stamp(integral_constant<int, 2>{}, t);
-        barrier();
-        stamp(integral_constant<int, 3>{}, t);
-        cluster(I1{}, split31 && n1 ? t + 1 : -1);          // C(t,0)
-        stamp(integral_constant<int, 4>{}, t);
-        barrier();
-        stamp(integral_constant<int, 5>{}, t);
-        if (!dbg_noread) reads(t, 1);                       // NC(t,1)
-        if (has_p2) { piece(I2{}, t_p2); load_piece(I3{}, I0{}, t_p2); if (!split31) load_piece(I3{}, I1{}, t_p2); }
-        stamp(integral_constant<int, 6>{}, t);
-        wait_lgkmcnt<0>();
-        if (wr == 1 && !(last && pf_resid)) {               // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
-            if (split31 && n2) wait_vmcnt<3>(); else wait_vm(n2);
-        }
-        stamp(integral_constant<int, 7>{}, t);
-        barrier();
-        stamp(integral_constant<int, 8>{}, t);
-        cluster(I3{}, split31 && has_p2 ? t_p2 : -1);       // C(t,1)
-        stamp(integral_constant<int, 9>{}, t);
-        if (wr == 0 && !(last && pf_resid)) wait_vm(n1);    // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
-        stamp(integral_constant<int, 10>{}, t);
-        barrier();
-        stamp(integral_constant<int, 11>{}, t);
-    }
-    if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
-    if (pf_resid) {
-        wait_vmcnt<0>();                                    // the throw-away loads have written their register
-        asm volatile("" :: "v"(pf_sink));
-    }
-    if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
-    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
-                        ((uintptr_t)p.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)p.bias % 16 == 0) && ((uintptr_t)p.resid % 16 == 0);
-    gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
-    if constexpr (STAMP) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's stores have left the wave
-        tile_ts[3] = __builtin_amdgcn_s_memtime();
-        if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) {
-            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + (wave >> 2) * 16;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) o[i] = ts[i];
-        }
-        // whole-tile timeline of a third-round workgroup (steady state): slots 32.. of the resid buffer
-        if (blockIdx.x == 2 * 256 + 40 && lane == 0 && (wave & 3) == 0) {
-            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + 32 + (wave >> 2) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = tile_ts[i];
-        }
-    }
-}
-
-static int ilog2_exact(int v) {
-    if (v <= 0) return -1;
-    int s = 0;
-    while ((1 << s) < v) ++s;
-    return ((1 << s) == v) ? s : -2;
-}
-
-// SPRC_GEMM_TILE: 0 = automatic (default), 2 = 128x128, 4 = 256x256
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? (int)strtol(e, nullptr, 0) : dflt;
-}
-constexpr int MAX_DEVICES = 64;
-static int current_device() {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return dev >= 0 && dev < MAX_DEVICES ? dev : 0;
-}
-static int num_cus() {                      // per device: a process may drive several GPUs
-    static int n[MAX_DEVICES] = {0};
-    const int dev = current_device();
-    if (n[dev] == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
-        if (n[dev] <= 0) n[dev] = 256;
-    }
-    return n[dev];
-}
-// hipFuncSetAttribute applies to the function ON THE CURRENT DEVICE: opt in once per (kernel instantiation, device)
-template <typename K>
-static void optin_lds(K kern, int bytes, bool (&done)[MAX_DEVICES]) {
-    const int dev = current_device();
-    if (!done[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        done[dev] = true;
-    }
-}
-
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT>
-static int launch_cfg(GemmParams p, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = 2 * (BM + BN) * 128;
-    // (A persistent variant -- grid = CUs x residency with the next tile's first K-tile prefetched before the epilogue --
-    // measured equal to one workgroup per tile on MI355X while costing ~45 VGPRs: all tiles take the same time, so the
-    // CUs stay in lockstep and the output-write bursts still coincide.  Removed.)
-    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN>;
-    static bool attr_set[MAX_DEVICES] = {false};
-    optin_lds(kern, LDS, attr_set);
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    static const int order = env_int("SPRC_GEMM_ORDER", 0);     // 8-m grouped order is better for the K-heavy 128x128 GEMMs
-    p.order = order;
-    const int nwg = p.tiles_m * p.tiles_n;
-    p.nwg0 = nwg;
-    hipLaunchKernelGGL(kern, dim3(nwg * (p.ksplit > 1 ? p.ksplit : 1) * (p.dual ? 2 : 1)), dim3(64 * WM * WN), LDS, st, p);
-    SPRC_CHECK_LAUNCH("sprc_gemm");
-    return SPRC_OK;
-}
-
-template <typename T, typename OutT, int ACT, bool MAX32>
-static int launch_anti(GemmParams p, hipStream_t st) {
-    constexpr int LDS = 2 * 512 * 128;
-    constexpr bool FP8 = sizeof(T) == 1;
-    auto kern = gemm_anti_kernel<OutT, ACT, MAX32, false, FP8>;
-    if constexpr (std::is_same<OutT, bf16_t>::value && ACT == SPRC_ACT_NONE && !MAX32 && !FP8) {
-        if ((p.debug & 64) && p.resid != nullptr) {         // phase-timestamp build (tools/gemm_stamp.py)
-            auto sk = gemm_anti_kernel<OutT, ACT, MAX32, true>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            p.tiles_m = (p.M + 255) / 256;
-            p.tiles_n = (p.N + 255) / 256;
-            p.order = 4;
-            p.ksplit = env_int("SPRC_GEMM_STAMP_MASK", 0xfff);
-            hipLaunchKernelGGL(sk, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS, st, p);
-            SPRC_CHECK_LAUNCH("sprc_gemm(anti, stamp)");
-            return SPRC_OK;
-        }
-    }
-    static bool attr_set[MAX_DEVICES] = {false};
-    optin_lds(kern, LDS, attr_set);
-    p.tiles_m = (p.M + 255) / 256;
-    p.tiles_n = (p.N + 255) / 256;
-    static const int order = env_int("SPRC_GEMM_ORDER", 4);     // W-resident groups of 4 n-tiles: +8 % on N = 9216, neutral else
-    p.order = order;
-    p.nwg0 = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(p.nwg0 * (p.dual ? 2 : 1)), dim3(512), LDS, st, p);
-    SPRC_CHECK_LAUNCH("sprc_gemm(anti)");
-    return SPRC_OK;
-}
-
-// The kernels address a tile with 32-bit offsets from its first row: the rows of one (<= 256-row) tile must span < 4 GiB.
-static bool fits_u32(const GemmParams& p) {
-    const int64_t span_a = p.a_shift < 0 ? 256 : (int64_t)((256 >> p.a_shift) + 2) * p.a_stride;
-    const int64_t kbytes = (int64_t)p.K * 4;
-    return span_a * p.lda_b + kbytes < ((int64_t)1 << 32) && 256 * p.ldw_b + kbytes < ((int64_t)1 << 32);
-}
-
-template <typename T, typename OutT, int ACT, bool MAX32>
-static int launch(const GemmParams& p, hipStream_t st) {
-    static const int forced = env_int("SPRC_GEMM_TILE", 0);
-    int cfg = forced;
-    if constexpr (sizeof(T) <= 2) {
-        if (cfg == 0) {
-            // Cost model in units of one 256x256xK tile on a CU (measured on MI355X, tools/gemm_shapes.py):
-            //   B  256x256 anti-phase kernel, one WG per CU:            rounds x 1
-            //   A  128x128 kernel, two co-resident WGs per CU:           full rounds of 2 x CUs tiles x 0.7, a last round of
-            //                                                            <= CUs tiles (one WG per CU, running alone) 0.42
-            //   C  B on the first Mm rows (Mm a multiple of 256) + A on the M - Mm remaining ones, + 0.08 for the extra launch
-            // C matters when a partial round of 256x256 tiles is nearly empty: the ViT GEMMs have M = 128 x 257 = 128.5 panels,
-            // so N = 1408 is 774 tiles = 3.02 rounds (fc2: 732 us whole, 562 + 77 us peeled); the Q-Former Q|K|V product of
-            // 233 fused queries is 531 tiles = 2.07 rounds (peel three panels: 504 tiles + 90 small ones).
-            const int ncu = num_cus();
-            const int64_t tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
-            // a short reduction with an fp32 + residual epilogue spends as long writing out (an HBM burst no other workgroup
-            // on the CU can hide) as in its K loop: +35 % per round (14912 x 768 x 768: 46 us on 256x256, 40 on 128x128;
-            // 32896 x 1024 x 1024: 131 us peeled, 118 on 128x128)
-            const double f256 = (p.K <= 1024 && sizeof(OutT) == 4 && p.resid != nullptr) ? 1.35 : 1.0;
-            const int64_t mult = p.dual ? 2 : 1;                 // a paired launch carries two products
-            auto cost256 = [&](int m) { return f256 * (double)((mult * ((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
-            auto cost128 = [&](int m) {
-                const int64_t t = mult * ((m + 127) / 128) * tn128, full = t / (2 * ncu), last = t % (2 * ncu);
-                return 0.7 * (double)full + (last == 0 ? 0.0 : last <= ncu ? 0.42 : 0.7);
-            };
-            const double cA = cost128(p.M), cB = cost256(p.M);
-            static const int peel = env_int("SPRC_GEMM_PEEL", 1);
-            const bool can_peel = peel && !MAX32 && !p.dual && p.M > 256 && p.a_shift < 0 && p.c_shift < 0;
-            double cC = 1e30;
-            int Mm = 0;
-            if (can_peel) {
-                for (int j = 0; j <= 12; ++j) {                        // peel the partial panel plus j whole ones
-                    const int m = (p.M / 256 - j) * 256;
-                    if (m <= 0 || m == p.M) continue;
-                    const double c = cost256(m) + cost128(p.M - m) + 0.08;
-                    if (c < cC - 1e-9) { cC = c; Mm = m; }
-                }
-            }
-            const int rem = p.M - Mm;
-            if (cC < 0.95 * (cA < cB ? cA : cB)) {
-                GemmParams pm = p, pt = p;
-                pm.M = Mm;
-                pt.M = rem;
-                pt.A = p.A + (int64_t)Mm * p.lda_b;
-                pt.C = reinterpret_cast<char*>(p.C) + (int64_t)Mm * p.ldc * (MAX32 ? 4 : (int64_t)sizeof(OutT));
-                if (p.resid != nullptr) pt.resid = p.resid + (int64_t)Mm * p.ldr;
-                const int rc = launch_anti<T, OutT, ACT, MAX32>(pm, st);
-                if (rc != SPRC_OK) return rc;
-                // remainder rows: a long reduction on a handful of workgroups is latency-bound (11 WGs x 96 K-tiles = 77 us
-                // for the ViT fc2) -> split K over 8 workgroups per tile into caller scratch and reduce in a fixed order
-                constexpr int S = 8;
-                if (rem <= 128 && p.K >= 4096 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.scratch != nullptr &&
-                    p.scratch_elems >= (int64_t)S * rem * p.N) {
-                    GemmParams ps = pt;
-                    ps.C = p.scratch; ps.ldc = p.N; ps.bias = nullptr; ps.resid = nullptr; ps.ldr = 0; ps.w_scale = nullptr;
-                    ps.ksplit = S; ps.split_stride = (int64_t)rem * p.N;
-                    const int rs = launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 2>(ps, st);
-                    if (rs != SPRC_OK) return rs;
-                    const int64_t n = (int64_t)rem * (p.N / 4);
-                    hipLaunchKernelGGL((splitk_reduce_kernel<OutT, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                                       p.scratch, S, ps.split_stride, rem, p.N, p.bias, pt.resid, p.ldr,
-                                       reinterpret_cast<OutT*>(pt.C), p.ldc, p.w_scale, p.a_scale, p.out_scale);
-                    SPRC_CHECK_LAUNCH("sprc_gemm(split-K reduce)");
-                    return SPRC_OK;
-                }
-                return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(pt, st);
-            }
-            cfg = cB <= cA ? 4 : 2;
-        }
-        // 256x256 tile: anti-phase schedule by default (SPRC_GEMM_TILE=14 forces the lock-step kernel for A/B runs)
-        if (cfg == 4 || cfg == 10) return launch_anti<T, OutT, ACT, MAX32>(p, st);
-    } else {
-        if (cfg == 0) cfg = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024 ? 4 : 2;
-    }
-    if (cfg == 4 || cfg == 10 || cfg == 14) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
-    return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(p, st);
-}
-
-template <typename T>
-static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st) {
-    if constexpr (sizeof(T) != 1) { if (a->max32) return launch<T, float, SPRC_ACT_NONE, true>(p, st); }
-    if (a->out_dtype == SPRC_F16) {                     // residual-branch delta (validated by the caller: bf16 operands, plain epilogue)
-        if constexpr (sizeof(T) == 2) return launch<T, f16_t, SPRC_ACT_NONE, false>(p, st);
-        else { set_error("sprc_gemm: SPRC_F16 output needs bf16 operands"); return SPRC_EUNSUPPORTED; }
-    }
-    if constexpr (sizeof(T) == 1) {                     // fp8 operands: the three epilogues of the fp8 ViT path
-        if (a->out_dtype == SPRC_FP8) {
-            switch (a->act) {
-                case SPRC_ACT_NONE: return launch<T, fp8_t, SPRC_ACT_NONE, false>(p, st);
-                case SPRC_ACT_GELU: return launch<T, fp8_t, SPRC_ACT_GELU, false>(p, st);
-                case SPRC_ACT_QUICKGELU: return launch<T, fp8_t, SPRC_ACT_QUICKGELU, false>(p, st);
-            }
-        }
-        if (a->act == SPRC_ACT_NONE && a->out_dtype == SPRC_BF16) return launch<T, bf16_t, SPRC_ACT_NONE, false>(p, st);
-        if (a->act == SPRC_ACT_NONE && a->out_dtype == SPRC_F32) return launch<T, float, SPRC_ACT_NONE, false>(p, st);
-        set_error("sprc_gemm(fp8): unsupported epilogue (act %d, out_dtype %d)", a->act, a->out_dtype);
-        return SPRC_EUNSUPPORTED;
-    } else {
-        if (a->out_dtype == SPRC_FP8) { set_error("sprc_gemm: SPRC_FP8 output needs fp8 operands"); return SPRC_EUNSUPPORTED; }
-    }
-    const bool o16 = a->out_dtype == SPRC_BF16;
-    switch (a->act) {
-        case SPRC_ACT_NONE:
-            return o16 ? launch<T, bf16_t, SPRC_ACT_NONE, false>(p, st) : launch<T, float, SPRC_ACT_NONE, false>(p, st);
-        case SPRC_ACT_GELU:
-            return o16 ? launch<T, bf16_t, SPRC_ACT_GELU, false>(p, st) : launch<T, float, SPRC_ACT_GELU, false>(p, st);
-        case SPRC_ACT_QUICKGELU:
-            return o16 ? launch<T, bf16_t, SPRC_ACT_QUICKGELU, false>(p, st)
-                       : launch<T, float, SPRC_ACT_QUICKGELU, false>(p, st);
-    }
-    set_error("sprc_gemm: unknown activation %d", a->act);
-    return SPRC_EINVAL;
-}
-
+int gemm_dispatch_bf16(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st) { return dispatch<bf16_t>(a, p, st); }
 }  // namespace sprc
 
 static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stream s) {
@@ -994,8 +71,8 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     const double np = b != nullptr ? 2.0 : 1.0;
     ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * a->K,
                    np * (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))));
-    if (a->dtype == SPRC_FP8) return dispatch<fp8_t>(a, p, st);
-    return a->dtype == SPRC_BF16 ? dispatch<bf16_t>(a, p, st) : dispatch<float>(a, p, st);
+    if (a->dtype == SPRC_FP8) return gemm_dispatch_fp8(a, p, st);
+    return a->dtype == SPRC_BF16 ? gemm_dispatch_bf16(a, p, st) : gemm_dispatch_f32(a, p, st);
 }
 
 extern "C" int sprc_gemm(const sprc_gemm_args* a, sprc_stream s) { return gemm_impl(a, nullptr, s); }

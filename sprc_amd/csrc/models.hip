@@ -107,9 +107,9 @@ static int attn(hipStream_t st, int dt, int B, int H, int Tq, int Tk, int dh, co
 // GEMM epilogue burst to the row kernels -- i.e. +0.3 % images/s, while the fp16 rounding of every branch output (2^-11
 // relative, not averaged over K like the bf16 operand roundings) takes the full-depth ViT-g cosine error from 4.3e-4 to
 // 1.1e-3, over the 1e-3 bar.  Kept as an A/B switch; off.
-static bool fuse_add_enabled() {
+static bool fuse_add_enabled(int which = 1) {            // bit 0: ViT blocks, bit 1: Q-Former layers
     static const int on = [] { const char* e = getenv("SPRC_FUSE_ADD"); return e ? atoi(e) : 0; }();
-    return on != 0;
+    return (on & which) != 0;
 }
 
 #define RUN(x)                      \
@@ -172,7 +172,7 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
     const bool split = with_enc && S > Lq;         // rows [:Lq] and [Lq:] take different paths
     // SPRC_FUSE_ADD=1: the post-LN residual adds (Qformer.py:294,380) ride on the LayerNorm kernels (sprc_layernorm add16),
     // the branch GEMMs write fp16 instead of running an fp32 + residual epilogue.  Off by default (see fuse_add_enabled).
-    const bool fuse_add = dt == SPRC_BF16 && fuse_add_enabled();
+    const bool fuse_add = dt == SPRC_BF16 && fuse_add_enabled(2);
     for (int l = 0; l < m->n_layers; ++l) {
         const sprc_qf_layer& L = m->layers[l];
         // self-attention over all S rows
@@ -330,15 +330,20 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     const bool split = n_streams >= 2 && B >= 16 && dt == SPRC_BF16;
     const int B0 = split ? B / 2 : B;
     hipStream_t st2 = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     if (split) {
-        static hipStream_t helper = nullptr;
-        if (helper == nullptr) {
-            SPRC_REQUIRE(hipStreamCreateWithFlags(&helper, hipStreamNonBlocking) == hipSuccess, "sprc_vit_forward: cannot create the helper stream");
-            (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-            (void)hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+        // one helper stream + fork/join events PER DEVICE (streams and events belong to the device they were created on)
+        struct Helper { hipStream_t stream; hipEvent_t fork, join; };
+        static Helper helpers[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        Helper& hp = helpers[dev >= 0 && dev < 64 ? dev : 0];
+        if (hp.stream == nullptr) {
+            SPRC_REQUIRE(hipStreamCreateWithFlags(&hp.stream, hipStreamNonBlocking) == hipSuccess, "sprc_vit_forward: cannot create the helper stream");
+            (void)hipEventCreateWithFlags(&hp.fork, hipEventDisableTiming);
+            (void)hipEventCreateWithFlags(&hp.join, hipEventDisableTiming);
         }
-        st2 = helper;
+        st2 = hp.stream; ev_fork = hp.fork; ev_join = hp.join;
         (void)hipEventRecord(ev_fork, st);
         (void)hipStreamWaitEvent(st2, ev_fork, 0);
     }
@@ -358,7 +363,7 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     // it in place with its bf16 result) and the LN kernel adds it to the fp32 residual stream (sum32 = x) before the
     // statistics.  Off by default (see fuse_add_enabled: no net gain, and it costs parity).
     const bool fp8 = m->fp8 != 0;
-    const bool fuse_add = dt == SPRC_BF16 && !fp8 && fuse_add_enabled();
+    const bool fuse_add = dt == SPRC_BF16 && !fp8 && fuse_add_enabled(1);
     SPRC_REQUIRE(!fp8 || (dt == SPRC_BF16 && D % 128 == 0 && F % 128 == 0), "sprc_vit_forward: the fp8 path needs a bf16 model with width, mlp %% 128 == 0");
     SPRC_REQUIRE(!(fp8 && m->calib_amax), "sprc_vit_forward: calibrate on the bf16 model, not on the fp8 one");
     float* calib = (dt == SPRC_BF16 && !fp8) ? m->calib_amax : nullptr;
@@ -452,9 +457,9 @@ extern "C" int sprc_qformer_image(const sprc_qformer_model* m, const float* raw,
     return sprc_l2norm_rows(q.proj, m->embed_dim, feats, feats16, m->embed_dim, B * Lq, m->embed_dim, dt, st);
 }
 
-extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
-                                 const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
-                                 void* fusion16, void* ws, size_t ws_bytes, sprc_stream s) {
+static int qformer_fuse_impl(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
+                             const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
+                             void* fusion16, const float* prompt_tokens, float* loss_align, void* ws, size_t ws_bytes, sprc_stream s) {
     RUN(check_qf(m));
     SPRC_REQUIRE(ref_embeds && input_ids && attention_mask && fusion && ws && B > 0, "sprc_qformer_fuse: bad arguments");
     SPRC_REQUIRE(enc_tokens == 257, "sprc_qformer_fuse: enc_tokens=%d (sprc_qformer_workspace_bytes plans for 257)", enc_tokens);
@@ -481,6 +486,8 @@ extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_e
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
     RUN(qf_stack(m, st, q, B, S, &kvs, q.mask, q.h32, q.h16));
+    if (loss_align != nullptr)                  // training: mse(mean fused query token, mean prompt token)  (align_prompt.py:192-193)
+        RUN(sprc_align_mse(q.h32, (int64_t)S * Hd, Lq, Hd, prompt_tokens, B, loss_align, st));
     // pass 2: pass-1 query rows as query_embeds (re-LayerNormed by the embedding LN), no image (:341-346)
     e.query_embeds = q.h32; e.q_bstride = (int64_t)S * Hd;
     e.y32 = q.g32; e.y16 = q.g16;
@@ -490,6 +497,52 @@ extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_e
     const sprc_rowmap cls_row = {1, S, Lq};
     RUN(gemm(st, dt, SPRC_F32, B, m->embed_dim, Hd, q.g16, Hd, m->text_proj, q.proj, m->embed_dim, SPRC_ACT_NONE, nullptr, 0, cls_row));
     return sprc_l2norm_rows(q.proj, m->embed_dim, fusion, fusion16, m->embed_dim, B, m->embed_dim, dt, st);
+}
+
+extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
+                                 const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
+                                 void* fusion16, void* ws, size_t ws_bytes, sprc_stream s) {
+    return qformer_fuse_impl(m, ref_embeds, enc_tokens, input_ids, attention_mask, B, fusion, fusion16, nullptr, nullptr, ws, ws_bytes, s);
+}
+
+// ---- training forward: align_prompt.py:95-200, forward only ---------------------------------------
+extern "C" int sprc_qformer_fuse_train(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
+                                       const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
+                                       void* fusion16, const float* prompt_tokens, float* loss_align, void* ws, size_t ws_bytes,
+                                       sprc_stream s) {
+    SPRC_REQUIRE(prompt_tokens && loss_align, "sprc_qformer_fuse_train: prompt_tokens / loss_align missing");
+    return qformer_fuse_impl(m, ref_embeds, enc_tokens, input_ids, attention_mask, B, fusion, fusion16, prompt_tokens, loss_align, ws,
+                             ws_bytes, s);
+}
+
+extern "C" int sprc_qformer_text_only(const sprc_qformer_model* m, const float* prompt_tokens, const int64_t* input_ids,
+                                      const int64_t* attention_mask, int32_t B, float* feat, void* feat16, void* ws,
+                                      size_t ws_bytes, sprc_stream s) {
+    RUN(check_qf(m));
+    SPRC_REQUIRE(prompt_tokens && input_ids && attention_mask && feat && ws && B > 0, "sprc_qformer_text_only: bad arguments");
+    SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_qformer_text_only: workspace must be 256-byte aligned");
+    Bump b(ws, ws_bytes);
+    QfBufs q;
+    qf_plan(m, B, 0, b, q, false);
+    if (!b.ok) {
+        set_error("sprc_qformer_text_only: workspace too small (%zu bytes given)", ws_bytes);
+        return SPRC_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query, Lt = m->max_txt, S = Lq + Lt;
+    RUN(sprc_qformer_mask(attention_mask, q.mask, B, Lq, Lt, st));          // cat([ones(32), text mask]) as the reference passes it (:174-176)
+    sprc_qformer_embed_args e;
+    memset(&e, 0, sizeof(e));
+    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt; e.vocab = m->vocab; e.no_img = 1;
+    e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
+    e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
+    e.query_embeds = prompt_tokens; e.q_bstride = 0;
+    e.y32 = q.h32; e.y16 = q.h16;
+    RUN(sprc_qformer_embed(&e, st));
+    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.h32, q.h16));
+    const sprc_rowmap row0 = {1, S, 0};                                      // last_hidden_state[:, 0, :]  (:177-179)
+    RUN(gemm(st, dt, SPRC_F32, B, m->embed_dim, Hd, q.h16, Hd, m->text_proj, q.proj, m->embed_dim, SPRC_ACT_NONE, nullptr, 0, row0));
+    return sprc_l2norm_rows(q.proj, m->embed_dim, feat, feat16, m->embed_dim, B, m->embed_dim, dt, st);
 }
 
 // ---- stage-2 rerank: blip2_qformer_cir_rerank.py:399-445 ------------------------------------------

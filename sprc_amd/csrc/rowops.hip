@@ -170,7 +170,22 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc
     const int b = row / S, t = row % S;
     const int nch = p.hidden >> 2;
     RowRegs r;
-    if (t < p.Lq) {
+    if (p.no_img) {
+        // Qformer.py:88-104 (no_img): rows = [text[0] ; the Lq query rows ; text[1:]], and EVERY row gets its position t
+        if (t >= 1 && t <= p.Lq) {
+            load_row(r, p.query_embeds + (int64_t)b * p.q_bstride + (int64_t)(t - 1) * p.hidden, nch, lane);
+        } else {
+            int64_t id = p.input_ids[(int64_t)b * p.Lt + (t == 0 ? 0 : t - p.Lq)];
+            id = id < 0 ? 0 : (id >= p.vocab ? p.vocab - 1 : id);
+            load_row(r, p.word_emb + id * p.hidden, nch, lane);
+        }
+        RowRegs pe;
+        load_row(pe, p.pos_emb + (int64_t)t * p.hidden, nch, lane);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            r.v[c].x += pe.v[c].x; r.v[c].y += pe.v[c].y; r.v[c].z += pe.v[c].z; r.v[c].w += pe.v[c].w;
+        }
+    } else if (t < p.Lq) {
         load_row(r, p.query_embeds + (int64_t)b * p.q_bstride + (int64_t)t * p.hidden, nch, lane);
     } else {
         const int pos = t - p.Lq;
@@ -342,6 +357,82 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void itm_head_kernel(const flo
     }
 }
 
+// ---- training-forward losses (align_prompt.py:157-193) -------------------------------------------------------------------
+// loss = mean_b( logsumexp_n(sim[b,n] / temp) - sim[b,b] / temp ): F.cross_entropy(sim / temp, arange(B)).  One workgroup.
+__global__ __launch_bounds__(256) void contrastive_ce_kernel(const float* __restrict__ sim, int64_t ld, int B, float inv_temp, float* loss) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int b = wave; b < B; b += 4) {
+        const float* row = sim + (int64_t)b * ld;
+        float mx = -INFINITY;
+        for (int n = lane; n < B; n += 64) mx = fmaxf(mx, row[n] * inv_temp);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int n = lane; n < B; n += 64) se += expf(row[n] * inv_temp - mx);
+        se = wave_sum(se);
+        acc += (mx + logf(se)) - row[b] * inv_temp;
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) / (float)B;
+}
+
+// loss = mean over (b, d) of (mean_j h[b, j, d] - mean_j prompt[j, d])^2, j < Lq: F.mse_loss(fusion[:, :32].mean(1), prompt.mean(1))
+__global__ __launch_bounds__(256) void align_mse_kernel(const float* __restrict__ h, int64_t sample_stride, int Lq, int D,
+                                                        const float* __restrict__ prompt, int B, float* loss) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    RowRegs pm, r;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) pm.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < Lq; ++j) {
+        load_row(r, prompt + (int64_t)j * D, nch, lane);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { pm.v[c].x += r.v[c].x; pm.v[c].y += r.v[c].y; pm.v[c].z += r.v[c].z; pm.v[c].w += r.v[c].w; }
+    }
+    float acc = 0.f;
+    const float inv = 1.0f / (float)Lq;
+    for (int b = wave; b < B; b += 4) {
+        RowRegs hm;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) hm.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < Lq; ++j) {
+            load_row(r, h + (int64_t)b * sample_stride + (int64_t)j * D, nch, lane);
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) { hm.v[c].x += r.v[c].x; hm.v[c].y += r.v[c].y; hm.v[c].z += r.v[c].z; hm.v[c].w += r.v[c].w; }
+        }
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const float dx = (hm.v[c].x - pm.v[c].x) * inv, dy = (hm.v[c].y - pm.v[c].y) * inv;
+            const float dz = (hm.v[c].z - pm.v[c].z) * inv, dw = (hm.v[c].w - pm.v[c].w) * inv;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        acc += wave_sum(q);
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) / ((float)B * (float)D);
+}
+
+extern "C" int sprc_contrastive_ce(const float* sim, int64_t ld, int32_t B, float temp, float* loss, sprc_stream s) {
+    SPRC_REQUIRE(sim && loss && B > 0 && temp > 0.f && ld >= B, "sprc_contrastive_ce: bad arguments");
+    hipLaunchKernelGGL(contrastive_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, sim, ld, B, 1.0f / temp, loss);
+    SPRC_CHECK_LAUNCH("sprc_contrastive_ce");
+    return SPRC_OK;
+}
+
+extern "C" int sprc_align_mse(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* prompt, int32_t B, float* loss,
+                              sprc_stream s) {
+    SPRC_REQUIRE(h && prompt && loss && B > 0 && Lq > 0, "sprc_align_mse: bad arguments");
+    SPRC_REQUIRE(D % 4 == 0 && D <= 64 * 4 * MAXC && sample_stride % 4 == 0, "sprc_align_mse: D=%d unsupported", D);
+    hipLaunchKernelGGL(align_mse_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, h, sample_stride, Lq, D, prompt, B, loss);
+    SPRC_CHECK_LAUNCH("sprc_align_mse");
+    return SPRC_OK;
+}
+
 extern "C" int sprc_itm_head(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* w, const float* b, int32_t P,
                              float* prob, sprc_stream s) {
     SPRC_REQUIRE(h && w && b && prob && P > 0 && Lq > 0, "sprc_itm_head: bad arguments");
@@ -356,6 +447,7 @@ extern "C" int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream 
     SPRC_REQUIRE(a && a->query_embeds && a->gamma && a->beta, "sprc_qformer_embed: null pointer");
     SPRC_REQUIRE(a->B > 0 && a->Lq > 0 && a->Lt >= 0, "sprc_qformer_embed: bad shape");
     SPRC_REQUIRE(a->Lt == 0 || (a->input_ids && a->word_emb && a->pos_emb), "sprc_qformer_embed: text tables missing");
+    SPRC_REQUIRE(!a->no_img || a->Lt > 0, "sprc_qformer_embed: no_img needs text");
     SPRC_REQUIRE(a->hidden % 4 == 0 && a->hidden <= 64 * 4 * MAXC, "sprc_qformer_embed: hidden=%d unsupported", a->hidden);
     const int rows = a->B * (a->Lq + a->Lt);
     const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);

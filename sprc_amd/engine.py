@@ -29,8 +29,8 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def rowmap(rows_per_group: int = 0, group_stride: int = 0, group_offset: int = 0) -> L.RowMap:
@@ -172,6 +172,18 @@ def rank_of(sim: torch.Tensor, listed: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+def _on_device(fn):
+    """Run an Engine method with the engine's GPU current: the library's launches, stream lookups and per-device kernel
+    attributes all refer to the current device (a process may hold engines on several GPUs)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class Engine:
     """Packed weights + workspaces for one model on one GPU."""
 
@@ -320,8 +332,11 @@ class Engine:
         self.itm_b = self._f32(sd["itm_head.bias"]) if "itm_head.bias" in sd else None
         m.layers = C.cast(layers, C.POINTER(L.QfLayer))
         self._qf_layers, self.qf = layers, m
+        # learned prompt tokens of the training losses (align_prompt.py:76-79, :170-193)
+        self.prompt_tokens = self._f32(sd["prompt_tokens"].reshape(q.num_query, q.hidden)) if "prompt_tokens" in sd else None
 
     # ---- fp8 calibration ---------------------------------------------------------------------
+    @_on_device
     def calibrate_fp8(self, images: torch.Tensor) -> torch.Tensor:
         """amax[depth, 3] = max |x| of the inputs of the qkv / fc1 / fc2 GEMMs of every block over `images`, collected by
         sprc_vit_forward on THIS (bf16) engine; feed it to Engine(..., dtype="fp8", fp8_amax=...)."""
@@ -347,6 +362,7 @@ class Engine:
         return ws
 
     # ---- forward passes ----------------------------------------------------------------------
+    @_on_device
     def vit_forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """raw[B,257,D] fp32 = ln_vision(ViT(images))."""
         v = self.cfg.vit
@@ -359,9 +375,10 @@ class Engine:
             n = min(self.max_batch, B - s)
             ws = self._workspace("vit", n)
             L.check(self.lib.sprc_vit_forward(C.byref(self.vit), images[s:s + n].data_ptr(), n, raw[s:s + n].data_ptr(),
-                                              ws.data_ptr(), ws.numel(), _stream()), "sprc_vit_forward")
+                                              ws.data_ptr(), ws.numel(), _stream(self.device)), "sprc_vit_forward")
         return raw
 
+    @_on_device
     def qformer_image(self, raw: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """feats[B,32,E] fp32 (unit rows) + compute-dtype copy (bf16 mode)."""
         raw = raw.to(device=self.device, dtype=torch.float32).contiguous()
@@ -375,9 +392,10 @@ class Engine:
             ws = self._workspace("qf", n)
             L.check(self.lib.sprc_qformer_image(C.byref(self.qf), raw[s:s + n].data_ptr(), n, feats[s:s + n].data_ptr(),
                                                 None if f16 is None else f16[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
-                                                _stream()), "sprc_qformer_image")
+                                                _stream(self.device)), "sprc_qformer_image")
         return feats, f16
 
+    @_on_device
     def qformer_fuse(self, ref_embeds: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor):
         """fusion[B,E] fp32 (unit rows) + compute-dtype copy (bf16 mode)."""
         ref = ref_embeds.to(device=self.device, dtype=torch.float32).contiguous()
@@ -398,7 +416,7 @@ class Engine:
             L.check(self.lib.sprc_qformer_fuse(C.byref(self.qf), ref[s:s + n].data_ptr(), ref.shape[1], ids[s:s + n].data_ptr(),
                                                mask[s:s + n].data_ptr(), n, fusion[s:s + n].data_ptr(),
                                                None if f16 is None else f16[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
-                                               _stream()), "sprc_qformer_fuse")
+                                               _stream(self.device)), "sprc_qformer_fuse")
         return fusion, f16
 
     # ---- stage-2 rerank ------------------------------------------------------------------
@@ -406,6 +424,7 @@ class Engine:
     def kv_width(self) -> int:
         return self.qf.n_cross * 2 * self.cfg.qformer.hidden
 
+    @_on_device
     def encode_kv(self, raw: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """kv[B, tokens, n_cross*2*hidden] (compute dtype): cross-attention K|V projections of image tokens, once per image."""
         raw = raw.to(device=self.device, dtype=torch.float32).contiguous()
@@ -421,9 +440,10 @@ class Engine:
             if ws is None or ws.numel() < need:
                 ws = self._ws["kv"] = torch.empty(need, dtype=torch.uint8, device=self.device)
             L.check(self.lib.sprc_qformer_encode_kv(C.byref(self.qf), raw[s:s + n].data_ptr(), n, T, kv[s:s + n].data_ptr(),
-                                                    ws.data_ptr(), ws.numel(), _stream()), "sprc_qformer_encode_kv")
+                                                    ws.data_ptr(), ws.numel(), _stream(self.device)), "sprc_qformer_encode_kv")
         return kv
 
+    @_on_device
     def itm(self, kv_a: torch.Tensor, index_a: torch.Tensor, kv_b: torch.Tensor, index_b: torch.Tensor,
             input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         """prob[P] = P(match) of P (query, candidate) pairs: pair p attends over cat(kv_a[index_a[p]], kv_b[index_b[p]])."""
@@ -452,5 +472,39 @@ class Engine:
                                               kv_a.data_ptr(), kv_a.shape[1], ia[s:s + n].data_ptr(),
                                               kv_b.data_ptr(), kv_b.shape[1], ib[s:s + n].data_ptr(),
                                               ids[s:s + n].data_ptr(), mask[s:s + n].data_ptr(), n, prob[s:s + n].data_ptr(),
-                                              ws.data_ptr(), ws.numel(), _stream()), "sprc_qformer_itm")
+                                              ws.data_ptr(), ws.numel(), _stream(self.device)), "sprc_qformer_itm")
         return prob
+
+    # ---- training forward (forward only) ------------------------------------------------------
+    @_on_device
+    def training_losses(self, image: torch.Tensor, target: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                        temp: float = 0.07) -> Dict[str, torch.Tensor]:
+        """The three losses of `Blip2QformerCirAlignPrompt.forward` (align_prompt.py:95-200), eval semantics:
+        loss_itc = CE(max-cosine(fusion, target feats) / temp), loss_rtc = CE(max-cosine(text-only prompt feat, target feats) / temp),
+        loss_align = MSE(mean fused query token of pass 1, mean prompt token).  No autograd history (no backward kernels)."""
+        if self.prompt_tokens is None:
+            raise L.SprcError("the state dict has no prompt_tokens: the training losses need them (align_prompt.py:76-79)")
+        B = image.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} > max_batch {self.max_batch}")
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        raw_ref, raw_tgt = self.vit_forward(image), self.vit_forward(target)
+        target_feats, _ = self.qformer_image(raw_tgt)
+        E_ = self.cfg.embed_dim
+        fusion = torch.empty((B, E_), dtype=torch.float32, device=self.device)
+        tfeat = torch.empty((B, E_), dtype=torch.float32, device=self.device)
+        losses = torch.zeros(3, dtype=torch.float32, device=self.device)
+        ws = self._workspace("qf", B)
+        st = _stream(self.device)
+        L.check(self.lib.sprc_qformer_fuse_train(C.byref(self.qf), raw_ref.data_ptr(), raw_ref.shape[1], ids.data_ptr(), mask.data_ptr(), B,
+                                                 fusion.data_ptr(), None, self.prompt_tokens.data_ptr(), losses[2:].data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), st), "sprc_qformer_fuse_train")
+        L.check(self.lib.sprc_qformer_text_only(C.byref(self.qf), self.prompt_tokens.data_ptr(), ids.data_ptr(), mask.data_ptr(), B,
+                                                tfeat.data_ptr(), None, ws.data_ptr(), ws.numel(), st), "sprc_qformer_text_only")
+        sim = torch.empty((2, B, B), dtype=torch.float32, device=self.device)
+        sim_max(fusion, target_feats, out=sim[0])
+        sim_max(tfeat, target_feats, out=sim[1])
+        for i in range(2):
+            L.check(self.lib.sprc_contrastive_ce(sim[i].data_ptr(), B, B, float(temp), losses[i:].data_ptr(), st), "sprc_contrastive_ce")
+        return {"loss_itc": losses[0], "loss_rtc": losses[1], "loss_align": losses[2]}

@@ -15,7 +15,8 @@ Deliberate differences from the reference (documented in DESIGN.md):
   * eval semantics always (dropout = identity).  The reference's CIRR scripts leave the Q-Former in
     train mode, which makes their features stochastic.
   * `inference` always returns a 2-D [B,N] tensor (the reference's `.squeeze()` collapses B=1 / N=1).
-  * `forward` (the three training losses, align_prompt.py:95-200) is out of scope.
+  * `forward` (the three training losses, align_prompt.py:95-200) is forward-only: values match the reference in eval
+    mode, but there are no backward kernels.
 """
 from __future__ import annotations
 
@@ -190,9 +191,16 @@ class Blip2QformerCirAlignPrompt(nn.Module):
                                  tok.attention_mask.repeat_interleave(T, dim=0))
         return prob.view(nq, T)
 
+    @torch.no_grad()
     def forward(self, samples):
-        raise NotImplementedError("training forward (align_prompt.py:95-200) is outside the retrieval hot path "
-                                  "(SURVEY.md section 8(f) N4)")
+        """Training forward, align_prompt.py:95-200: {"image", "target", "text_input"} -> {"loss_itc", "loss_rtc", "loss_align"}
+        computed by the HIP engine with eval semantics (dropout = identity).  FORWARD ONLY: the losses carry no autograd
+        history -- there are no backward kernels, so `blip_fine_tune_2.py`'s `.backward()` has
+        nothing to differentiate; use it for loss evaluation / monitoring."""
+        image, target, text = samples["image"], samples["target"], samples["text_input"]
+        tok = self.tokenizer(list(text), padding="max_length", truncation=True, max_length=self.max_txt_len,
+                             return_tensors="pt").to(self.device)
+        return self.engine().training_losses(image, target, tok.input_ids, tok.attention_mask, temp=float(self.temp))
 
 
 # ---- registry + loader (lavis/common/registry.py:83-110, lavis/models/__init__.py:204-249) -----------

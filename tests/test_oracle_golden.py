@@ -176,3 +176,17 @@ def test_rerank_matches_reference(golden_dir):
     np.testing.assert_allclose(prob.numpy(), g["prob"], atol=TOL, rtol=0)
     np.testing.assert_allclose(one.numpy(), g["prob_one"], atol=TOL, rtol=0)
     assert np.all((g["prob"] > 0) & (g["prob"] < 1)) and np.ptp(g["prob"]) > 0.02
+
+
+def test_training_losses_match_reference(golden_dir):
+    """N4: the oracle's training forward (three losses) against the reference's Blip2QformerCirAlignPrompt.forward."""
+    g = np.load(golden_dir / "train_eva.npz", allow_pickle=False)
+    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    B = int(g["batch"])
+    images = synth.make_images(2 * B, seed=int(g["seed"]))
+    np.testing.assert_array_equal(images[:, :, 0, :4].numpy(), g["image_probe"])
+    with torch.no_grad():
+        out = O.training_losses(sd, cfg, images[:B], images[B:], torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]))
+    for k in ("loss_itc", "loss_rtc", "loss_align"):
+        assert float(out[k]) == pytest.approx(float(g[k]), abs=2e-5), k

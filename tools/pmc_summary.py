@@ -1,50 +1,60 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 counter passes of tools/pmc_kernel.sh: pmc_summary.py OUTDIR MATCH [command text].
-Writes OUTDIR/summary.json = {counters: {name: {n, mean, sum}}, derived: {...}} for the kernels whose name contains MATCH."""
+MATCH is one kernel-name substring, or several classes "name=substr,name=substr" (each summarised separately from the same
+passes).  Writes OUTDIR/summary.json = {class: {match, counters: {name: {n, mean, sum}}, derived: {...}}}."""
 import collections
 import csv
 import glob
 import json
 import sys
 
-O, match = sys.argv[1], sys.argv[2]
+O, match_arg = sys.argv[1], sys.argv[2]
 cmd = sys.argv[3] if len(sys.argv) > 3 else ""
-acc = collections.defaultdict(list)
-for f in glob.glob(f"{O}/p*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
+classes = dict(c.split("=", 1) for c in match_arg.split(",")) if "=" in match_arg else {match_arg: match_arg}
+rows_c = [r for f in glob.glob(f"{O}/p*/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f))]
+rows_t = [r for f in glob.glob(f"{O}/kt/**/*kernel_trace.csv", recursive=True) for r in csv.DictReader(open(f))]
+
+
+def summarise(match):
+    acc = collections.defaultdict(list)
+    for r in rows_c:
         if match in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for f in glob.glob(f"{O}/kt/**/*kernel_trace.csv", recursive=True)
-       for r in csv.DictReader(open(f)) if match in r["Kernel_Name"]]
-s = {k: {"n": len(v), "mean": sum(v) / len(v), "sum": sum(v)} for k, v in sorted(acc.items())}
-d = {}
+    dur = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rows_t if match in r["Kernel_Name"]]
+    s = {k: {"n": len(v), "mean": sum(v) / len(v), "sum": sum(v)} for k, v in sorted(acc.items())}
+    d = {}
+
+    def m(k):
+        return s[k]["mean"] if k in s else None
+
+    if dur:
+        d["mean_duration_us"] = sum(dur) / len(dur) / 1e3
+        d["total_duration_ms"] = sum(dur) / 1e6
+        d["dispatches_timed"] = len(dur)
+    if m("GRBM_GUI_ACTIVE") and dur:
+        d["effective_clock_GHz"] = m("GRBM_GUI_ACTIVE") / 8 / (sum(dur) / len(dur))      # the counter is summed over the 8 XCDs
+    if m("SQ_VALU_MFMA_BUSY_CYCLES") and m("GRBM_GUI_ACTIVE"):
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA), summed over the chip's 1024 SIMDs
+        d["mfma_busy_frac"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (m("GRBM_GUI_ACTIVE") / 8)
+    if m("SQ_LDS_BANK_CONFLICT") is not None and m("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac"] = m("SQ_LDS_BANK_CONFLICT") / m("SQ_LDS_IDX_ACTIVE")
+    if m("SQ_WAVE_CYCLES"):
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+            if m(k) is not None:
+                d[k.lower() + "_frac_of_wave_cycles"] = m(k) / m("SQ_WAVE_CYCLES")
+    if m("FETCH_SIZE") is not None:
+        d["fetch_bytes_per_dispatch_x2"] = 2.0 * 1024.0 * m("FETCH_SIZE")                # KiB; doubled: MI355X_MICROARCH.md HBM section
+    if m("WRITE_SIZE") is not None:
+        d["write_bytes_per_dispatch"] = 1024.0 * m("WRITE_SIZE")
+    if dur and "fetch_bytes_per_dispatch_x2" in d:
+        d["hbm_side_GBs"] = (d["fetch_bytes_per_dispatch_x2"] + d.get("write_bytes_per_dispatch", 0.0)) / (sum(dur) / len(dur))
+    return {"match": match, "counters": s, "derived": d}
 
 
-def m(k):
-    return s[k]["mean"] if k in s else None
-
-
-if dur:
-    d["mean_duration_us"] = sum(dur) / len(dur) / 1e3
-    d["dispatches_timed"] = len(dur)
-if m("GRBM_GUI_ACTIVE") and dur:
-    d["effective_clock_GHz"] = m("GRBM_GUI_ACTIVE") / 8 / (sum(dur) / len(dur))      # the counter is summed over the 8 XCDs
-if m("SQ_VALU_MFMA_BUSY_CYCLES") and m("GRBM_GUI_ACTIVE"):
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 bf16 MFMA), summed over the chip's 1024 SIMDs
-    d["mfma_busy_frac"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (m("GRBM_GUI_ACTIVE") / 8)
-if m("SQ_LDS_BANK_CONFLICT") is not None and m("SQ_LDS_IDX_ACTIVE"):
-    d["lds_bank_conflict_frac"] = m("SQ_LDS_BANK_CONFLICT") / m("SQ_LDS_IDX_ACTIVE")
-if m("SQ_WAVE_CYCLES"):
-    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
-        if m(k) is not None:
-            d[k.lower() + "_frac_of_wave_cycles"] = m(k) / m("SQ_WAVE_CYCLES")
-if m("FETCH_SIZE") is not None:
-    d["fetch_bytes_per_dispatch_x2"] = 2.0 * 1024.0 * m("FETCH_SIZE")                # KiB; doubled: MI355X_MICROARCH.md HBM section
-if m("WRITE_SIZE") is not None:
-    d["write_bytes_per_dispatch"] = 1024.0 * m("WRITE_SIZE")
-if dur and "fetch_bytes_per_dispatch_x2" in d:
-    d["hbm_side_GBs"] = (d["fetch_bytes_per_dispatch_x2"] + d.get("write_bytes_per_dispatch", 0.0)) / (sum(dur) / len(dur))
-json.dump({"match": match, "command": cmd, "counters": s, "derived": d}, open(f"{O}/summary.json", "w"), indent=1)
-for k, v in s.items():
-    print(f"{k:30s} n={v['n']:4d} mean={v['mean']:16.1f}")
-print(json.dumps(d, indent=1))
+out = {"command": cmd, "classes": {c: summarise(mt) for c, mt in classes.items()}}
+json.dump(out, open(f"{O}/summary.json", "w"), indent=1)
+for c, v in out["classes"].items():
+    print(f"== {c} ({v['match']})")
+    for k, x in v["counters"].items():
+        print(f"  {k:30s} n={x['n']:5d} mean={x['mean']:16.1f}")
+    print(json.dumps(v["derived"], indent=1))

@@ -35,7 +35,11 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
     out[c] = {k: {"kb_total": v[0], "dispatches": v[1], "kb_per_dispatch": v[0] / max(v[1], 1)} for k, v in acc.items()}
 g_f = out["FETCH_SIZE"].get("gemm", {}); g_w = out["WRITE_SIZE"].get("gemm", {})
+import sys
+sys.path.insert(0, "$R")
+import bench
 summary = {
+    "kernel_source_sha": bench.kernel_source_sha(),
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE over 'bench.py $ARGS' (separate passes, counters only)",
     "units": "counters are KiB; FETCH_SIZE doubled (gfx950 counts the 128-B requests of wide coalesced reads at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported (uncalibrated)",
     "raw": out,
