@@ -102,8 +102,10 @@ def test_model_surface_and_checkpoint_keys():
     from sprc_amd import _lib
     with pytest.raises(_lib.SprcError, match="no CPU fallback"):
         m.extract_target_features(torch.zeros(1, 3, 224, 224))
-    with pytest.raises(NotImplementedError):
-        m({"image": None})
+    with pytest.raises(_lib.SprcError, match="no CPU fallback"):           # forward (training losses) also runs on the HIP engine only
+        m.tokenizer = lambda text, **kw: __import__("sprc_amd.tokenizer", fromlist=["TokenBatch"]).TokenBatch(
+            torch.zeros((1, 32), dtype=torch.int64), torch.ones((1, 32), dtype=torch.int64))
+        m({"image": torch.zeros(1, 3, 224, 224), "target": torch.zeros(1, 3, 224, 224), "text_input": ["x"]})
     with pytest.raises(KeyError):
         load_model_and_preprocess("blip2_cir_rerank_learn", "pretrain")
 
