@@ -268,15 +268,32 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
 // (4) global addresses of a thread's pieces advance by a constant per tile.
 constexpr float RESCALE_LOG2 = 8.0f;
 
-template <int DHP, bool ONES>
-__global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int nqb, int xcd_map, int debug) {
+// Bounds-checked 16-B loads through a raw buffer descriptor (non-template helpers: this hipcc drops the host stub of a kernel
+// TEMPLATE whose dependent code calls the buffer builtins directly).  A lane whose offset lies outside [0, bytes - 16] reads
+// zeros: padded keys, the zero columns of the 96-wide tile and idle lanes need NO branch -- every load of a tile is
+// straight-line code, so the compiler can count them (`s_waitcnt vmcnt(N)`) instead of draining the queue at each branch
+// (which had serialised the double-buffered prefetch: one exposed ~2-us round trip per key tile).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const char* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 attn_load16(__amdgpu_buffer_rsrc_t rs, uint32_t voffset) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffset, 0, 0));
+}
+constexpr uint32_t ATTN_OOB = 0x80000000u;   // beyond every descriptor's range (an image's K/V rows span < 2 GiB)
+
+template <int DHP, bool ONES, int NW, bool ABLATE = false>
+__global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, int nqb, int xcd_map, int debug_arg) {
+    // the production instantiation folds every ablation branch away: a run-time branch around the loads or the tile math makes
+    // the compiler merge its wait counters at the join and drain the whole load queue there
+    const int debug = ABLATE ? debug_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 192, KS = DHP / 16, DT = DHP / 32, CPR = DHP / 8;
+    constexpr int NT = 64 * NW, KS = DHP / 16, DT = DHP / 32, CPR = DHP / 8;
     constexpr int KROW = DHP * 2 + 16;        // bytes per K row in LDS (conflict-free ds_read_b128 across 32 rows)
     constexpr int VROW = 32 * 2 + 8;          // bytes per V^T row of one 32-key tile
     constexpr int KBYTES = 32 * KROW, BUF = KBYTES + DHP * VROW;
     constexpr int KPT = (32 * CPR + NT - 1) / NT;              // 16-B K pieces per thread per tile
     static_assert(16 * CPR <= NT, "one (key pair, chunk) item of V per thread");
+    static_assert(NW * 32 * (DHP * 2 + 16) <= 160 * 1024, "output strips fit in LDS");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, half = lane >> 5;
     // Block b runs on XCD b % 8.  A token row of the packed qkv tensor holds the K (V) slices of ALL heads back to back
@@ -292,49 +309,51 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
     const bool ragged = (p.Tk & 31) != 0;
 
     // ---- this thread's share of a tile: KPT 16-B pieces of K, one (key pair, 8-wide chunk) item of V ----
-    const char* kptr[KPT];
-    bool k_on[KPT];
+    // descriptors cover this (image, head): rows [0, Tk) of head_dim*2 valid bytes each (the last row bounds the range)
+    const __amdgpu_buffer_rsrc_t rs_k = attn_rsrc(p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2,
+                                                  (uint32_t)((int64_t)(p.Tk - 1) * p.ldk * 2 + dh * 2));
+    const __amdgpu_buffer_rsrc_t rs_v = attn_rsrc(p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2,
+                                                  (uint32_t)((int64_t)(p.Tk - 1) * p.ldv * 2 + dh * 2));
+    uint32_t k_off[KPT];
     int k_row[KPT], k_lds[KPT];
 #pragma unroll
     for (int u = 0; u < KPT; ++u) {
         const int idx = tid + u * NT, c = idx % CPR;
         k_row[u] = idx / CPR;
-        k_on[u] = k_row[u] < 32 && c * 8 < dh;                   // columns >= head_dim stay zero (pad of the 96-wide tile)
         k_lds[u] = k_row[u] * KROW + c * 16;
-        kptr[u] = p.k + (((int64_t)b * p.Tk + min(k_row[u], 31)) * p.ldk + (int64_t)h * dh) * 2 + c * 16;
+        // columns >= head_dim stay zero (pad of the 96-wide tile); rows >= 32 belong to no piece
+        k_off[u] = (k_row[u] < 32 && c * 8 < dh) ? (uint32_t)(k_row[u] * p.ldk * 2 + c * 16) : ATTN_OOB;
     }
     // consecutive lanes take consecutive 16-B chunks of ONE row (like K): with lanes running over the key pairs instead, a
     // wave instruction touched 16 different rows (16-32 cache lines for 1 KB)
     const int v_kp = tid / CPR, v_c = tid % CPR;
-    const bool v_item = v_kp < 16, v_on = v_item && v_c * 8 < dh;
+    const bool v_item = v_kp < 16;
     const bool v_ones = ONES && v_item && v_c * 8 == dh;         // this thread owns V^T rows dh .. dh+7: row dh = ones
-    const char* vptr = p.v + (((int64_t)b * p.Tk + v_kp * 2) * p.ldv + (int64_t)h * dh) * 2 + v_c * 16;
-    const int64_t kstep = 32 * p.ldk * 2, vstep = 32 * p.ldv * 2, vnext = p.ldv * 2;
+    // V^T rows are 18 dwords apart, so the eight rows of chunk c, c+4 and c+8 start on the same banks and the 32-bit
+    // transposing writes of a wave were 3-way conflicted (SQ_LDS_BANK_CONFLICT 45 % of the LDS cycles).  Key-pair column kp of
+    // rows 32..63 / 64..95 is stored at kp ^ 8 / kp ^ 4: at most 2-way (free for ds_write_b32); the fragment reads apply the
+    // same constant per 32-row tile (it permutes their four 8-byte pieces, at no cost).
+    const int v_col = (v_kp ^ (((v_c >> 2) & 1) * 8) ^ (((v_c >> 3) & 1) * 4)) * 4;
+    uint32_t v_off = (v_item && v_c * 8 < dh) ? (uint32_t)(v_kp * 2 * p.ldv * 2 + v_c * 16) : ATTN_OOB;
+    const uint32_t kstep = 32 * p.ldk * 2, vstep = 32 * p.ldv * 2, vnext = p.ldv * 2;
     // Two staging register sets: the loads of tile t+2 are issued while tile t is computed and tile t+1 waits in the other
     // set (ablation: with one set -- loads issued one tile ahead -- the kernel ran 175 us, 108 us with the loop's loads
     // removed, 148 us with the MATH removed: a chain of nine exposed ~2-us memory round trips per workgroup).
     struct Stage { u32x4 kreg[KPT], va, vb; };
     Stage stg[2];
-    auto fetch = [&](Stage& g, int kt, auto tail_) {             // tail: the tile may hold keys >= Tk
-        constexpr bool TAIL = decltype(tail_)::value;
+    auto fetch = [&](Stage& g) {                                 // the next tile in key order: branch-free, rows >= Tk read zeros
 #pragma unroll
         for (int u = 0; u < KPT; ++u) {
-            g.kreg[u] = u32x4{0u, 0u, 0u, 0u};
-            if (k_on[u] && (!TAIL || kt * 32 + k_row[u] < p.Tk)) g.kreg[u] = *reinterpret_cast<const u32x4*>(kptr[u]);
-            kptr[u] += kstep;
+            g.kreg[u] = attn_load16(rs_k, k_off[u]);
+            k_off[u] += kstep;
         }
-        g.va = g.vb = u32x4{0u, 0u, 0u, 0u};
-        if (v_on) {
-            const int t0 = kt * 32 + v_kp * 2;
-            if (!TAIL || t0 < p.Tk) g.va = *reinterpret_cast<const u32x4*>(vptr);
-            if (!TAIL || t0 + 1 < p.Tk) g.vb = *reinterpret_cast<const u32x4*>(vptr + vnext);
-        }
-        vptr += vstep;
+        g.va = attn_load16(rs_v, v_off);
+        g.vb = attn_load16(rs_v, v_off + vnext);
+        v_off += vstep;
     };
-    auto fetch_any = [&](Stage& g, int kt) {                     // tile kt if it exists (the last one may be ragged)
-        if (kt >= nkt) return;
-        if (ragged && kt + 1 == nkt) fetch(g, kt, std::true_type{}); else fetch(g, kt, std::false_type{});
-    };
+    // issued unconditionally, also past the last tile (those rows read zeros at no memory cost): a branch around the loads
+    // makes the compiler drain the whole queue (`s_waitcnt vmcnt(0)`) where the paths join
+    auto fetch_any = [&](Stage& g, int) { fetch(g); };
     auto commit = [&](Stage& g, int buf) {
         u32x4 va = g.va, vb = g.vb;
         char* sK = smem + buf * BUF;
@@ -347,8 +366,8 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {                     // rows (e, e+1) of the chunk: low / high halves of dword e/2
                 const uint32_t a = va[e >> 1], c = vb[e >> 1];
-                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e) * VROW + v_kp * 4) = (a & 0xffffu) | (c << 16);
-                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e + 1) * VROW + v_kp * 4) = (a >> 16) | (c & 0xffff0000u);
+                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e) * VROW + v_col) = (a & 0xffffu) | (c << 16);
+                *reinterpret_cast<uint32_t*>(sV + (v_c * 8 + e + 1) * VROW + v_col) = (a >> 16) | (c & 0xffff0000u);
             }
         }
     };
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
     fetch_any(stg[1], 1);
 
     // Q^T fragments (B operand): lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8]
-    const int qt = qb * 3 + wave;
+    const int qt = qb * NW + wave;
     const int qrow = min(qt * 32 + r32, p.Tq - 1);
     const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
     bf16x8 qf[KS];
@@ -388,6 +407,8 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
         const char* krow = sK + r32 * KROW + half * 16;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            // (issuing all KS fragment reads ahead of the first MFMA through inline asm changed nothing: 124-127 us either way --
+            // with three waves per SIMD the other waves cover the read latency)
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 32);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         }
@@ -425,17 +446,23 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
             pf[j] = __builtin_bit_cast(bf16x8, pk);
         }
         if constexpr (!ONES) l_run += psum;
+        u32x4 vf[DT][2];                        // V^T fragments: issued together, ahead of the softmax arithmetic's tail
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const char* vrow = sV + (dt * 32 + r32) * VROW + (4 * half) * 2;
+            const int x = ((dt & 1) * 8) ^ ((dt >> 1) * 4);          // column swizzle of this 32-row tile, in key pairs (4 B)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (16 * j) * 2);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (16 * j + 8) * 2);
-                const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j], o[dt], 0, 0, 0);
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + ((8 * j) ^ x) * 4);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + ((8 * j + 4) ^ x) * 4);
+                vf[dt][j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
         }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[dt][j]), pf[j], o[dt], 0, 0, 0);
     };
 
     commit(stg[0], 0);
@@ -469,7 +496,7 @@ __global__ __launch_bounds__(192, 3) void attn_stream_kernel(AttnParams p, int n
     // transposes its 32 x head_dim tile through a private strip of the (now idle) K/V buffers and writes whole rows as
     // 16-B pieces: 5.5 instructions per lane, 176 contiguous bytes per row.
     constexpr int ORS = DHP * 2 + 16;         // strip row stride: 16-B aligned, 2-way bank conflicts at most
-    static_assert(3 * 32 * ORS <= 2 * BUF, "output strips fit in the K/V buffers");
+    // (the launch sizes LDS for max(K/V buffers, NW output strips))
     __syncthreads();                          // every wave is done reading K/V tiles
     char* so = smem + wave * (32 * ORS);
 #pragma unroll
@@ -578,16 +605,18 @@ static int launch_bf16(const AttnParams& p, hipStream_t st) {
     return SPRC_OK;
 }
 
-template <int DHP, bool ONES>
+template <int DHP, bool ONES, int NW>
 static int launch_stream(const AttnParams& p, hipStream_t st) {
     constexpr int BUF = 32 * (DHP * 2 + 16) + DHP * 72;
-    const int nqb = ((p.Tq + 31) / 32 + 2) / 3;
+    constexpr int LDS = 2 * BUF > NW * 32 * (DHP * 2 + 16) ? 2 * BUF : NW * 32 * (DHP * 2 + 16);
+    const int nqb = ((p.Tq + 31) / 32 + NW - 1) / NW;
     const int bh = p.B * p.H;
     // SPRC_ATTN_DEBUG (timing ablations, WRONG results): 1 no global loads in the loop, 2 no LDS commit, 4 no tile math, 8 no barrier
     static const int debug = [] { const char* e = getenv("SPRC_ATTN_DEBUG"); return e ? atoi(e) : 0; }();
     static const int xcd = [] { const char* e = getenv("SPRC_ATTN_XCD"); return e ? atoi(e) : 1; }();
     const int xmap = !xcd ? 0 : (xcd == 3 && (bh % 8) == 0) ? 1 : (p.B % 8) == 0 ? 2 : (bh % 8) == 0 ? 1 : 0;
-    hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES>), dim3(bh * nqb), dim3(192), 2 * BUF, st, p, nqb, xmap, debug);
+    if (debug != 0) hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES, NW, true>), dim3(bh * nqb), dim3(64 * NW), LDS, st, p, nqb, xmap, debug);
+    else hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES, NW, false>), dim3(bh * nqb), dim3(64 * NW), LDS, st, p, nqb, xmap, 0);
     SPRC_CHECK_LAUNCH("sprc_attention(bf16, streaming)");
     return SPRC_OK;
 }
@@ -622,9 +651,11 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
         // (SPRC_ATTN_STREAM=0 keeps the resident-K/V kernel for A/B runs)
         static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
         if (stream && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
-            if (a->head_dim <= 64) return launch_stream<64, false>(p, st);
-            if (a->head_dim == 88) return launch_stream<96, true>(p, st);      // denominator from the ones row of the padded V^T tile
-            return launch_stream<96, false>(p, st);
+            static const int nw = [] { const char* e = getenv("SPRC_ATTN_WAVES"); return e ? atoi(e) : 3; }();
+            if (a->head_dim <= 64) return nw == 5 ? launch_stream<64, false, 5>(p, st) : nw == 9 ? launch_stream<64, false, 9>(p, st) : launch_stream<64, false, 3>(p, st);
+            if (a->head_dim == 88)                                             // denominator from the ones row of the padded V^T tile
+                return nw == 5 ? launch_stream<96, true, 5>(p, st) : nw == 9 ? launch_stream<96, true, 9>(p, st) : launch_stream<96, true, 3>(p, st);
+            return launch_stream<96, false, 3>(p, st);
         }
         // 257 tokens = 9 query tiles: nine waves (one tile each, the K / V staging shared by nine) beat eight waves of which
         // one carries two tiles: 209 -> 195 us per ViT-g layer (SPRC_ATTN_NINE=0 for the A/B)
