@@ -881,9 +881,17 @@ static int launch(const GemmParams& p, hipStream_t st) {
                     SPRC_CHECK_LAUNCH("sprc_gemm(split-K reduce)");
                     return SPRC_OK;
                 }
+                if constexpr (sizeof(T) == 2 && !MAX32) {
+                    if (((rem + 127) / 128) * tn128 <= ncu) return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(pt, st);
+                }
                 return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(pt, st);
             }
             cfg = cB <= cA ? 4 : 2;
+            // a 128x128 grid that cannot even give every CU one workgroup is latency-bound (12-48 K-tiles on a fraction of the
+            // chip): 64x64 tiles (32 KB LDS, four workgroups per CU) spread it 4x wider.  Measured: 4096x768x768 17.6 -> 12.7 us,
+            // 4096x768x3072 44.9 -> 37.6, the 128-row remainders of the ViT products 18.3 -> 11.4-12.2; grids above one
+            // workgroup per CU (7456x768x768, 4096x2304x768) are equal or slower on 64x64 and keep 128x128.
+            if (cfg == 2 && !MAX32 && sizeof(T) == 2 && mult * ((p.M + 127) / 128) * tn128 <= ncu) cfg = 1;
         }
         // 256x256 tile: anti-phase schedule by default (SPRC_GEMM_TILE=14 forces the lock-step kernel for A/B runs)
         if (cfg == 4 || cfg == 10) return launch_anti<T, OutT, ACT, MAX32>(p, st);
@@ -891,6 +899,9 @@ static int launch(const GemmParams& p, hipStream_t st) {
         if (cfg == 0) cfg = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024 ? 4 : 2;
     }
     if (cfg == 4 || cfg == 10 || cfg == 14) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
+    if constexpr (sizeof(T) == 2 && !MAX32) {
+        if (cfg == 1) return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(p, st);     // 64 x 64 tile, 32 KB LDS: small latency-bound products
+    }
     return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(p, st);
 }
 
