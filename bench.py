@@ -32,11 +32,12 @@ sys.path.insert(0, ROOT)
 GALLERY, QUERIES, BATCH, TOPK = 2297, 4181, 128, 51
 Q_PER_STEP = (BATCH * QUERIES + GALLERY - 1) // GALLERY          # 233 -> keep CIRR-val's query:image ratio
 MFMA_BF16_PEAK_TFLOPS = 2500.0                                    # dense bf16, MI355X_MICROARCH.md
+MFMA_FP8_PEAK_TFLOPS = 5000.0                                     # dense fp8 (MX-scaled K = 128 / 64 instructions), same table
 HBM_PEAK_GBS = 8000.0
 # the GEMM class = every launch of these kernels (sprc_amd/csrc/gemm.hip); the 256x256 anti-phase kernel carries > 95 % of
 # the class time at the bench shapes, the 128x128 kernel the remainder rows and the small Q-Former products
 GEMM_KERNELS = {"bf16": "sprc::gemm_anti_kernel<...> (256x256 anti-phase, dominant) + sprc::gemm_kernel<bf16,...> (128x128)",
-                "fp8": "sprc::gemm_anti_kernel<..., FP8> (256x256 anti-phase, e4m3 operands: ViT qkv / fc1 / fc2) + the bf16 kernels (proj, Q-Former)",
+                "fp8": "sprc::gemm_anti_kernel<..., FP8> (256x256 anti-phase, MX-scaled e4m3 MFMA: ViT qkv / fc1 / fc2) + the bf16 kernels (proj, Q-Former)",
                 "fp32": "sprc::gemm_kernel<float,...> (exact fp32 MFMA)"}
 
 
@@ -231,9 +232,10 @@ def main():
         # the library pipelines the two halves of a batch on two streams, so launches of one class can overlap in time: the
         # class time is the UNION of the launches' HIP-event intervals (busy_ms); the plain sum is reported next to it
         ach = pe.flops / (pe.busy_ms * 1e-3) / 1e12 if pe.busy_ms > 0 else 0.0
-        # fp8: the kernels issue the NON-scaled e4m3 MFMA (v_mfma_f32_32x32x16_fp8_fp8), which runs at the bf16 rate: 2.5 PF is
-        # its ceiling; the 5 PF fp8 figure belongs to the MX-scaled K = 128 instruction, which this build does not use
-        peak = 157.3 if a.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS
+        # fp8: the ViT's qkv / fc1 / fc2 products (85-92 % of the class flops) issue the MX-scaled e4m3 MFMA
+        # (v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales): the class is priced against the 5 PF dense fp8 peak,
+        # although proj and the Q-Former products in the same class run on bf16 operands
+        peak = 157.3 if a.dtype == "fp32" else MFMA_FP8_PEAK_TFLOPS if a.dtype == "fp8" else MFMA_BF16_PEAK_TFLOPS
         kernels = {n: {"ms_per_step": round(prof[j].busy_ms / n_prof, 3), "sum_launch_ms_per_step": round(prof[j].ms / n_prof, 3),
                        "launches_per_step": prof[j].launches // n_prof,
                        "tflops": round(prof[j].flops / max(prof[j].busy_ms, 1e-9) / 1e9, 1),

@@ -162,6 +162,53 @@ __device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x
     return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b1, a1, c, 0, 0, 0);
 }
 
+// MX-scaled e4m3 MFMA with unit block scales (E8M0 127 = 2^0): v_mfma_scale_f32_32x32x64_f8f6f4 covers K = 64 per instruction
+// at TWICE the rate of the non-scaled fp8 / bf16 instructions (5 PF dense).  A lane supplies 32 bytes = two 16-B fragments
+// of the bf16 LDS layout; with all scales 1 the k-order inside the 64 is a free permutation shared by both operands.
+// SPRC_FP8_MX 0 falls back to two non-scaled 32x32x16 steps per fragment (bf16 rate).
+#ifndef SPRC_FP8_MX
+#define SPRC_FP8_MX 1
+#endif
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ f32x16 mfma_mx(const u32x4& b0, const u32x4& b1, const u32x4& a0, const u32x4& a1, f32x16 c) {
+    const i32x8 bb = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
+    const i32x8 aa = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bb, aa, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
+// One K-tile of the 128x128 kernel on MX fp8: two K = 64 steps, each from a PAIR of 16-B fragments per operand row-tile; the
+// second pair is read and the next K-tile's loads are issued before the MFMAs of the first.
+template <int TM, int TN, int KT_BYTES, typename Issue>
+__device__ __forceinline__ void pipe_ktile_mx(uint32_t a_base, uint32_t b_base, uint32_t c0, f32x16 (&acc)[TM][TN], Issue&& issue) {
+    static_assert(KT_BYTES == 128, "two K = 64 steps per K-tile");
+    u32x4 fa[2][2][TM], fb[2][2][TN];           // [pair][fragment in pair][row-tile]
+    auto read_pair = [&](auto p_) {
+        constexpr int pr = decltype(p_)::value;
+        static_for<0, 2>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            const uint32_t cn = c0 ^ ((2 * pr + k) << 5), an = a_base + cn, bn = b_base + cn;
+            static_for<0, TM>([&](auto i) { fa[pr][k][decltype(i)::value] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(an); });
+            static_for<0, TN>([&](auto i) { fb[pr][k][decltype(i)::value] = lds_read128<decltype(i)::value * 32 * KT_BYTES>(bn); });
+        });
+    };
+    read_pair(std::integral_constant<int, 0>{});
+    static_for<0, 2>([&](auto p_) {
+        constexpr int pr = decltype(p_)::value;
+        if constexpr (pr == 0) read_pair(std::integral_constant<int, 1>{});
+        issue(std::integral_constant<int, 2 * pr>{});
+        issue(std::integral_constant<int, 2 * pr + 1>{});
+        if constexpr (pr == 0) wait_lgkmcnt<2 * (TM + TN)>();
+        else wait_lgkmcnt<0>();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+                acc[mi][ni] = mfma_mx(fb[pr][0][ni], fb[pr][1][ni], fa[pr][0][mi], fa[pr][1][mi], acc[mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+    });
+}
+
 template <int TM, int TN, int KT_BYTES, bool FP8, typename Issue>
 __device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base, uint32_t c0, f32x16 (&acc)[TM][TN],
                                                 Issue&& issue) {
@@ -421,10 +468,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
             if constexpr (sizeof(T) <= 2) {
                 char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
                 const uint32_t so = lds0 + (t & 1) * STAGE_BYTES;
-                pipe_ktile_bf16<TM, TN, KT_BYTES, sizeof(T) == 1>(so + a_off, so + b_off, c0, acc, [&](auto kk_) {
+                auto issue = [&](auto kk_) {
                     constexpr int kk = decltype(kk_)::value;
                     if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
-                });
+                };
+                if constexpr (sizeof(T) == 1 && SPRC_FP8_MX) pipe_ktile_mx<TM, TN, KT_BYTES>(so + a_off, so + b_off, c0, acc, issue);
+                else pipe_ktile_bf16<TM, TN, KT_BYTES, sizeof(T) == 1>(so + a_off, so + b_off, c0, acc, issue);
             } else {
                 if (more) {
                     char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
@@ -602,11 +651,19 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     // 16 MFMAs: k-steps 2h, 2h+1 of the 128 x 64 wave tile; when `tile` >= 0 the SECOND load of piece q goes out mid-cluster
     auto cluster = [&](auto q_, int tile) {
         __builtin_amdgcn_s_setprio(1);
-        static_for<0, 16>([&](auto x_) {
-            constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
-            acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
-            if constexpr (x == 7) { if (tile >= 0) load_piece(q_, I1{}, tile); }
-        });
+        if constexpr (FP8 && SPRC_FP8_MX) {                  // 8 MX MFMAs (K = 64 each): the cluster lasts as long as 16 bf16 ones
+            static_for<0, 8>([&](auto x_) {
+                constexpr int x = decltype(x_)::value, mi = x >> 1, ni = x & 1;
+                acc[mi][ni] = mfma_mx(fb[0][ni], fb[1][ni], fa[0][mi], fa[1][mi], acc[mi][ni]);
+                if constexpr (x == 3) { if (tile >= 0) load_piece(q_, I1{}, tile); }
+            });
+        } else {
+            static_for<0, 16>([&](auto x_) {
+                constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
+                acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
+                if constexpr (x == 7) { if (tile >= 0) load_piece(q_, I1{}, tile); }
+            });
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     auto wait_vm = [&](bool newer) {                        // leave the newest two pieces (4 loads) in flight, if issued

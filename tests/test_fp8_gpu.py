@@ -1,5 +1,6 @@
-"""fp8 (OCP e4m3fn) path -- BASELINE.json config C5 "ViT-L backbone, fp8 MFMA": GEMM with fp8 operands (per-tensor activation
-scale, per-output-channel weight scales, fp32 accumulation), LayerNorm with an fp8 operand copy, the calibration pass, and
+"""fp8 (OCP e4m3fn) path -- BASELINE.json config C5 "ViT-L backbone, fp8 MFMA": GEMM with fp8 operands on the MX-scaled
+v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; per-tensor activation scale and per-output-channel weight scales in the
+epilogue, fp32 accumulation), LayerNorm with an fp8 operand copy, the calibration pass, and
 the fp8 ViT inside the full pipeline against the REFERENCE goldens (bound measured and stated here)."""
 import math
 
