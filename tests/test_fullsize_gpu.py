@@ -159,3 +159,30 @@ def test_ranking_from_a_loaded_feature_store_is_bit_identical(scores, tmp_path):
     v1, i1 = E.topk(sim, K)
     v2, i2 = E.topk(sim2, K)
     assert torch.equal(i1, i2) and torch.equal(v1, v2)
+
+
+def test_c5_shard_bf16_ranking_at_scale():
+    """BASELINE.json config C5 per-GPU sizes: a 125 000-image shard (1 M / 8 GPUs) in bf16 against 512 queries: scores within bf16
+    noise of a float64 evaluation on samples, top-51 bit-exact against the oracle's stable order of the DEVICE scores, and the
+    8-way sharded merge of per-shard top-51 == the global top-51 (what ShardedRanker does over RCCL)."""
+    N, nq, k = 125_000, 512, 51
+    g = torch.Generator(device=DEV).manual_seed(5)
+    feats = torch.nn.functional.normalize(torch.randn((N, 32, 256), generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    fusion = torch.nn.functional.normalize(torch.randn((nq, 256), generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    sim = E.sim_max(fusion, feats)
+    assert sim.shape == (nq, N) and bool(torch.isfinite(sim).all())
+    rows, cols = torch.arange(0, nq, 97, device=DEV), torch.arange(0, N, 1013, device=DEV)
+    want = torch.einsum("qe,nje->qnj", fusion[rows].double(), feats[cols].double()).max(-1).values
+    np.testing.assert_allclose(sim[rows][:, cols].cpu().numpy(), want.cpu().numpy(), atol=2e-3, rtol=0)   # bf16 operands, fp32 accumulate
+    v, i = E.topk(sim, k)
+    s = sim.cpu().numpy()
+    want_v, want_i = O.topk_stable(s[::16], k)                               # every 16th query through the numpy oracle
+    np.testing.assert_array_equal(i.cpu().numpy()[::16], want_i.astype(np.int32))
+    np.testing.assert_array_equal(v.cpu().numpy()[::16], want_v)
+    cand_v, cand_i = [], []
+    for r in range(8):
+        lo, hi = shard_bounds(N, 8, r)
+        lv, li = E.topk(E.sim_max(fusion, feats[lo:hi].contiguous()), k, idx_base=lo)
+        cand_v.append(lv); cand_i.append(li)
+    mv, mi = E.topk(torch.cat(cand_v, 1).contiguous(), k, gidx=torch.cat(cand_i, 1).contiguous())
+    assert torch.equal(mi, i) and torch.equal(mv, v)
