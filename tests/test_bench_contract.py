@@ -1,5 +1,5 @@
-"""The bench line the driver parses: the committed `profiles/r01_bench_n1.json` (an unedited `python bench.py` line apart
-from `roofline.traffic`, which bench.py itself reads from profiles/r01_traffic.json) must carry every field of the
+"""The bench line the driver parses: the committed `profiles/r02_bench_n1.json` (an unedited `python bench.py` line apart
+from `roofline.traffic`, which bench.py itself reads from profiles/r02_traffic.json) must carry every field of the
 measurement contract, and the roofline numbers must be self-consistent."""
 import json
 from pathlib import Path
@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_committed_bench_line_follows_the_contract():
-    d = json.loads((ROOT / "profiles" / "r01_bench_n1.json").read_text())
+    d = json.loads((ROOT / "profiles" / "r02_bench_n1.json").read_text())
     base = json.loads((ROOT / "BASELINE.json").read_text())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -36,8 +36,28 @@ def test_committed_bench_line_follows_the_contract():
 
 def test_committed_rocprof_summary_agrees_with_the_bench_line():
     import csv
-    d = json.loads((ROOT / "profiles" / "r01_bench_n1.json").read_text())
-    rows = list(csv.DictReader((ROOT / "profiles" / "r01_bench_kernel_stats.csv").open()))
+    d = json.loads((ROOT / "profiles" / "r02_bench_n1.json").read_text())
+    rows = list(csv.DictReader((ROOT / "profiles" / "r02_bench_kernel_stats.csv").open()))
     gemm_ms = sum(float(r["TotalDurationNs"]) for r in rows if "gemm" in r["Name"] or "splitk" in r["Name"]) / 4e6   # 4 steps profiled
     ev = d["kernels"]["gemm_bf16"]["ms_per_step"]
     assert abs(gemm_ms - ev) / ev < 0.03, (gemm_ms, ev)
+
+
+def test_committed_counter_summary_has_the_utilisation_numbers():
+    d = json.loads((ROOT / "profiles" / "r02_pmc.json").read_text())
+    g = d["classes"]["gemm_anti"]["derived"]
+    for k in ("mfma_busy_frac", "effective_clock_GHz", "lds_bank_conflict_frac", "sq_wait_any_frac_of_wave_cycles", "hbm_side_GBs"):
+        assert k in g and g[k] > 0, k
+    assert 0.2 < g["mfma_busy_frac"] < 1.0 and 1.0 < g["effective_clock_GHz"] < 2.6
+    t = json.loads((ROOT / "profiles" / "r02_traffic.json").read_text())
+    b = json.loads((ROOT / "profiles" / "r02_bench_n1.json").read_text())
+    per_launch = t["gemm_bytes_per_step"]["total"] / b["kernels"]["gemm_bf16"]["launches_per_step"]
+    assert abs(per_launch - b["roofline"]["traffic"]) / per_launch < 1e-3
+    assert t["kernel_source_sha"][:12] in b["roofline"]["traffic_source"]
+
+
+def test_fp8_bench_line_is_priced_against_the_fp8_peak():
+    d = json.loads((ROOT / "profiles" / "r02_bench_vitL_fp8.json").read_text())
+    assert d["dtype"] == "fp8" and d["roofline"]["peak"] == 5000.0
+    b = json.loads((ROOT / "profiles" / "r02_bench_vitL_bf16.json").read_text())
+    assert d["value"] > b["value"]

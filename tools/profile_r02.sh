@@ -12,9 +12,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02
 mkdir -p $O
 cd $R
-python bench.py --steps 20 --warmup 5 > $O/bench_n1.log 2>&1; tail -1 $O/bench_n1.log > $O/bench_n1.json
 bash tools/profile_bench.sh r02/pb > $O/profile_bench.log 2>&1
 cp $O/pb/kernel_stats.csv $O/bench_kernel_stats.csv; cp $O/pb/traffic.json $O/traffic.json
+cp $O/traffic.json profiles/r02_traffic.json        # bench.py reads roofline.traffic from here (same box, same kernel sources)
+python bench.py --steps 20 --warmup 5 > $O/bench_n1.log 2>&1; tail -1 $O/bench_n1.log > $O/bench_n1.json
 bash tools/pmc_kernel.sh r02/pmc "gemm_anti=gemm_anti_kernel,gemm_128=gemm_kernel,attention=attn_,layernorm=layernorm_kernel" -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc.log 2>&1
 cp $O/pmc/summary.json $O/pmc.json
 for dt in bf16 fp8; do python bench.py --backbone pretrain_vitL --dtype $dt --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_vitL_$dt.json; done
