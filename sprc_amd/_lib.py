@@ -6,9 +6,11 @@ raises if the shared object is missing (build it with `python -m sprc_amd.build`
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libsprc_hip.so"
+# SPRC_LIB_PATH: an A/B build of the same library (tools/build_variant.sh); never a different implementation
+LIB_PATH = Path(os.environ.get("SPRC_LIB_PATH") or (Path(__file__).resolve().parent / "libsprc_hip.so"))
 
 SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: GEMM output only (residual deltas); FP8: OCP e4m3fn operands
 ABI_VERSION = 2
