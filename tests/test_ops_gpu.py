@@ -39,10 +39,10 @@ def test_gemm_bf16(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(2300, 4100, 64), (2300, 4100, 128), (2300, 4100, 192), (2300, 4100, 704),
-                                   (4224, 4096, 256), (4224 + 77, 4096, 320)])
+                                   (4224, 4096, 256), (4224 + 77, 4096, 320), (2300, 4100, 384), (2300, 4100, 448)])
 def test_gemm_bf16_256_tile_and_peel(M, N, K):
-    """Shapes the dispatcher sends to the 256x256 anti-phase kernel (ragged M and N; K = 1, 2, 3, 11 K-tiles: prologue, early
-    pieces and counted-vmcnt tails) and to the peeled split (first M & ~255 rows on 256x256, remainder on 128x128)."""
+    """Shapes the dispatcher sends to the 256x256 anti-phase kernel (ragged M and N; K = 1 .. 7 and 11 K-tiles: prologue, early
+    pieces, every steady-loop / run-time-tail split of the lean K loop, counted-vmcnt tails) and to the peeled split (first M & ~255 rows on 256x256, remainder on 128x128)."""
     A, W, b, r = _bf(_rand((M, K), 21)), _bf(_rand((N, K), 22, 0.05)), _rand((N,), 23), _rand((M, N), 24)
     ref = A.double() @ W.double().t() + b.double()
     out = E.gemm(A.to(DEV), W.to(DEV), bias=b.to(DEV), out_dtype=L.SPRC_F32).cpu()

@@ -27,4 +27,4 @@ for rep in range(3):
     tt = R.view(-1)[:128].view(torch.int64).cpu().numpy()[32:40]
     for g in range(2):
         t = tt[g * 4:g * 4 + 4]
-        print(f"   tile timeline (WG 552) G{g}: prologue {int(t[1] - t[0])}  K loop {int(t[2] - t[1])}  epilogue {int(t[3] - t[2])}  cycles")
+        print(f"   tile timeline (WG {os.environ.get('SPRC_GEMM_STAMP_WG', '552')}) G{g}: prologue {int(t[1] - t[0])}  K loop {int(t[2] - t[1])}  epilogue {int(t[3] - t[2])}  cycles")
