@@ -299,45 +299,63 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sv[e] *= p.a_scale;
             }
+            // Residual rows are fetched TWO 32-row blocks ahead of their use (the fragments' registers are free here): with the
+            // loads of a block issued only when the block was reached, every block paid a full memory round trip -- 23 k cycles
+            // for a tile alone on the chip, 45-50 k with 256 tiles in their epilogues at once (s_memtime, tools/epi_probe.sh).
+            // Loads are branch-free (clamped addresses; "is there a residual" selects one of two straight-line bodies): hipcc
+            // drains the memory queue wherever predicated loads meet.
+            // (C may alias the residual: every element is read by the lane that writes it, before it writes it.)
+            auto block_row = [&](int mi, int it) { return cm0 + (wr * TM + mi) * 32 + it * RPI + rsub; };
+            const int colc = col_ok ? col : 0;
+            auto body = [&](auto res_) {
+                constexpr bool RES = decltype(res_)::value;
+                f32x4 rv[2][ITERS];
+                auto load_resid = [&](int mi, f32x4 (&dst)[ITERS]) {
 #pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                // residual rows of this block first (C may alias it: every element is read by the lane that writes it)
-                f32x4 rv[ITERS];
-                int64_t prow[ITERS];
-                bool ok[ITERS];
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    const int row = cm0 + (wr * TM + mi) * 32 + it * RPI + rsub;
-                    ok[it] = row < p.M && col_ok;
-                    prow[it] = map_row_s(p.c_shift, p.c_stride, p.c_off, row < p.M ? row : 0);
-                    rv[it] = (p.resid != nullptr && ok[it]) ? *reinterpret_cast<const f32x4*>(p.resid + prow[it] * p.ldr + col)
-                                                           : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        *reinterpret_cast<f32x4*>(strip + r32 * LD + (ni * 32 + 8 * g + 4 * half) * 4) =
-                            f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
-#pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + rsub) * LD + ch * 16);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {           // element-wise on purpose: vector adds become v_pk_add_f32 (slower)
-                        if (scaled) v[e] *= sv[e];
-                        v[e] += bv[e];
-                        if constexpr (ACT == SPRC_ACT_GELU) {
-                            if constexpr (sizeof(T) <= 2) v[e] = gelu_fast(v[e]);
-                            else v[e] = gelu_erf(v[e]);
-                        }
-                        if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
-                        v[e] += rv[it][e];
-                        if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= p.out_scale;
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, min(block_row(mi, it), p.M - 1));
+                        dst[it] = *reinterpret_cast<const f32x4*>(p.resid + pr * p.ldr + colc);
                     }
-                    if (!ok[it]) continue;
-                    store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + prow[it] * p.ldc + col, v);
+                };
+                if constexpr (RES) {
+                    load_resid(0, rv[0]);
+                    if constexpr (TM > 1) load_resid(1, rv[1]);
                 }
-            }
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            *reinterpret_cast<f32x4*>(strip + r32 * LD + (ni * 32 + 8 * g + 4 * half) * 4) =
+                                f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + rsub) * LD + ch * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {       // element-wise on purpose: vector adds become v_pk_add_f32 (slower)
+                            if (scaled) v[e] *= sv[e];
+                            v[e] += bv[e];
+                            if constexpr (ACT == SPRC_ACT_GELU) {
+                                if constexpr (sizeof(T) <= 2) v[e] = gelu_fast(v[e]);
+                                else v[e] = gelu_erf(v[e]);
+                            }
+                            if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
+                            if constexpr (RES) v[e] += rv[mi & 1][it][e];
+                            if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= p.out_scale;
+                        }
+                        const int row = block_row(mi, it);
+                        if (!(row < p.M && col_ok)) continue;
+                        const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, row);
+                        store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v);
+                    }
+                    if constexpr (RES) {
+                        if (mi + 2 < TM) load_resid(mi + 2, rv[mi & 1]);
+                    }
+                }
+            };
+            if (p.resid != nullptr) body(std::true_type{});
+            else body(std::false_type{});
             return;
         }
     }
