@@ -41,7 +41,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
         return SPRC_EUNSUPPORTED;
     }
     if (!fits_u32(p)) {
-        set_error("sprc_gemm: a 256-row tile of A or W spans >= 4 GiB (lda=%lld ldw=%lld)", (long long)a->lda, (long long)a->ldw);
+        set_error("sprc_gemm: a 256-row tile of A or W spans >= 4 GiB, or a row stride >= 16 MiB (lda=%lld ldw=%lld)", (long long)a->lda, (long long)a->ldw);
         return SPRC_EUNSUPPORTED;
     }
     p.tiles_m = p.tiles_n = 0;

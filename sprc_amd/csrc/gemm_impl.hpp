@@ -260,14 +260,25 @@ __device__ __forceinline__ void tile_origin(int vb, int nwg, int tiles_m, int ti
     } else {
         const int GN = mode;                      // n-tiles per group
         const int in_group = GN * tiles_m;
-        const int first_n = (pid / in_group) * GN;
+        // (this runs before the first load of every tile: one float division instead of three integer ones -- all values
+        // are < 2^20, the quotient is exact after one correction step -- and shifts for the divisors that are 32 and 8
+        // everywhere but in the last group / last block)
+        int grp = (int)((float)pid * __builtin_amdgcn_rcpf((float)in_group));
+        int rem = pid - grp * in_group;
+        if (rem < 0) { --grp; rem += in_group; }
+        if (rem >= in_group) { ++grp; rem -= in_group; }
+        const int first_n = grp * GN;
         const int gsz = min(tiles_n - first_n, GN);
-        const int rem = pid % in_group;
         // inside a group: blocks of 8 m-tiles x gsz n-tiles, m fastest
-        const int blk = rem / (8 * gsz), inb = rem % (8 * gsz);
+        int blk, inb;
+        if (gsz == 4) { blk = rem >> 5; inb = rem & 31; }
+        else { blk = rem / (8 * gsz); inb = rem % (8 * gsz); }
         const int mrem = min(tiles_m - blk * 8, 8);
-        m0 = (blk * 8 + inb % mrem) * BM;
-        n0 = (first_n + inb / mrem) * BN;
+        int im, in;
+        if (mrem == 8) { im = inb & 7; in = inb >> 3; }
+        else { im = inb % mrem; in = inb / mrem; }
+        m0 = (blk * 8 + im) * BM;
+        n0 = (first_n + in) * BN;
     }
 }
 
@@ -603,6 +614,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int nt = FP8 ? p.K / 128 : p.K / 64;             // K-tiles of 128 bytes
     uint64_t tile_ts[4] = {0, 0, 0, 0};                      // STAMP build: entry | prologue done | K loop done | epilogue done
+    uint64_t pro_ts[3] = {0, 0, 0};                         // STAMP build, inside the prologue: setup done | loads issued | loads landed
     if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
 
     int vb = blockIdx.x;
@@ -613,12 +625,14 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     int m0, n0;
     tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
     f32x16 acc[TM][TN];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int mi = 0; mi < TM; ++mi)
+        for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
+            for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    };
     uint64_t ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // Two forms of the same K loop (identical schedule, waits and results).  bf16: the lean form.  fp8 (MX): the first form --
     // its 32-byte MFMA operands cost a register copy per fragment pair, the kernel sits at 256 VGPRs, and the lean form's
@@ -638,15 +652,23 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
         const char* a_base = p.A + a_row0 * p.lda_b;
         const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
+        // everything up to the first load is exposed once per tile (s_memtime: 2-3.5 k cycles of a 75 k tile before this diet):
+        // offsets are < 2^32 by fits_u32(), rows of a tile < 2^8 -> 24-bit multiplies on the plain row map
+        const bool plain_a = p.a_shift < 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int c = j * 256 + ltid, row = pc_row[q] + (c >> 3);
                 const int slot = (c & 7) ^ ((row >> 1) & 7);
-                const int64_t oa = (map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b;
-                const int64_t ow = (int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldw_b;
-                pc_off[q][j] = (uint32_t)(q >= 2 ? oa : ow) + slot * 16;
+                uint32_t o;
+                if (q >= 2) {
+                    if (plain_a) o = __umul24((uint32_t)(min(m0 + row, p.M - 1) - m0), (uint32_t)p.lda_b);
+                    else o = (uint32_t)((map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b);
+                } else {
+                    o = __umul24((uint32_t)(min(n0 + row, p.N - 1) - n0), (uint32_t)p.ldw_b);
+                }
+                pc_off[q][j] = o + slot * 16;
             }
         }
         const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a_base), rs_w = make_rsrc(w_base);
@@ -803,9 +825,16 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         };
         // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
         // flight, G1 one interval behind
+        if constexpr (STAMP) pro_ts[0] = __builtin_amdgcn_s_memtime();
         static_for<0, 4>([&](auto q_) { piece(q_, 0u, 0); });
-        if (wr == 1 && nt > 1) { piece(I2{}, PAR_BYTES, 1); piece(I3{}, PAR_BYTES, 1); wait_vmcnt<4>(); }
+        if constexpr (STAMP) pro_ts[1] = __builtin_amdgcn_s_memtime();
+        if (wr == 1 && nt > 1) { piece(I2{}, PAR_BYTES, 1); piece(I3{}, PAR_BYTES, 1); }
+        asm volatile("" ::: "memory");
+        zero_acc();                                         // 128 v_mov under the first loads' latency
+        asm volatile("" ::: "memory");
+        if (wr == 1 && nt > 1) wait_vmcnt<4>();
         else wait_vmcnt<0>();
+        if constexpr (STAMP) pro_ts[2] = __builtin_amdgcn_s_memtime();
         barrier();
         if (wr == 1) barrier();
         if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
@@ -823,6 +852,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             asm volatile("" :: "v"(pf_sink));
         }
     } else {
+        zero_acc();
         // piece q of this group: q = 0, 1 issued in NC(t,0), q = 2, 3 in NC(t,1):  G0: B0 B1 | A2 A3    G1: B2 B3 | A0 A1
         // (K-tile t+1, except G1's A0 A1 which already belong to K-tile t+2)
         const int ltid = tid & 255, wg = wave & 3;
@@ -998,6 +1028,8 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + 32 + (wave >> 2) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = tile_ts[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o[8 + i] = pro_ts[i];
         }
     }
 }
@@ -1095,7 +1127,8 @@ static int launch_anti(GemmParams p, hipStream_t st) {
 static bool fits_u32(const GemmParams& p) {
     const int64_t span_a = p.a_shift < 0 ? 256 : (int64_t)((256 >> p.a_shift) + 2) * p.a_stride;
     const int64_t kbytes = (int64_t)p.K * 4;
-    return span_a * p.lda_b + kbytes < ((int64_t)1 << 32) && 256 * p.ldw_b + kbytes < ((int64_t)1 << 32);
+    return span_a * p.lda_b + kbytes < ((int64_t)1 << 32) && 256 * p.ldw_b + kbytes < ((int64_t)1 << 32) &&
+           p.lda_b < (1 << 24) && p.ldw_b < (1 << 24);          // the 256 x 256 kernel forms row offsets with 24-bit multiplies
 }
 
 template <typename T, typename OutT, int ACT, bool MAX32>
@@ -1138,7 +1171,8 @@ static int launch(const GemmParams& p, hipStream_t st) {
                 }
             }
             const int rem = p.M - Mm;
-            if (cC < 0.95 * (cA < cB ? cA : cB)) {
+            // peel when it saves at least a quarter of a tile-round (the ViT fc1: 3096 tiles = 12.09 rounds -> 12 + 0.5)
+            if (cC + 0.25 < (cA < cB ? cA : cB)) {
                 GemmParams pm = p, pt = p;
                 pm.M = Mm;
                 pt.M = rem;

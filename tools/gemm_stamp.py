@@ -24,7 +24,8 @@ for rep in range(3):
         t = ts[g * 16:g * 16 + 12]
         d = "  ".join(f"{a}->{b}: {int(t[b] - t[a])}" for a, b in zip(live[:-1], live[1:]))
         print(f"mask {mask:#05x} rep{rep} G{g} :: {d}")
+    pp = R.view(-1)[:128].view(torch.int64).cpu().numpy()[40:48]
     tt = R.view(-1)[:128].view(torch.int64).cpu().numpy()[32:40]
     for g in range(2):
         t = tt[g * 4:g * 4 + 4]
-        print(f"   tile timeline (WG {os.environ.get('SPRC_GEMM_STAMP_WG', '552')}) G{g}: prologue {int(t[1] - t[0])}  K loop {int(t[2] - t[1])}  epilogue {int(t[3] - t[2])}  cycles")
+        print(f"   tile timeline (WG {os.environ.get('SPRC_GEMM_STAMP_WG', '552')}) G{g}: prologue {int(t[1] - t[0])}  K loop {int(t[2] - t[1])}  epilogue {int(t[3] - t[2])}  cycles  | prologue: setup {int(pp[g * 4] - t[0])}  issue {int(pp[g * 4 + 1] - pp[g * 4])}  land {int(pp[g * 4 + 2] - pp[g * 4 + 1])}  barrier {int(t[1] - pp[g * 4 + 2])}")
