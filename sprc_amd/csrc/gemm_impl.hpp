@@ -169,10 +169,29 @@ __device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x
 #ifndef SPRC_ANTI_LDPOS
 #define SPRC_ANTI_LDPOS 1          // the in-cluster load goes out after MFMA number LDPOS (0..15)
 #endif
+#ifndef SPRC_FP8_LEAN
+#define SPRC_FP8_LEAN 1            // 1: the fp8 instantiations of the 256 x 256 kernel use the lean K loop too
+#endif
 #ifndef SPRC_FP8_MX
 #define SPRC_FP8_MX 1
 #endif
 typedef __attribute__((ext_vector_type(8))) int i32x8;
+// volatile asm: as a pure intrinsic hipcc SINKS the MFMAs of a whole K-tile pair to the loop latch (legal, and fatal for the
+// interval structure); the statement stays where it is written.  Callers keep >= 8 other MFMAs between two uses of one
+// accumulator (no hazard nops are inserted for inline asm).
+__device__ __forceinline__ f32x16 mfma_mx8(const i32x8& bb, const i32x8& aa, f32x16 c) {
+    const int one = 0x7f7f7f7f;                             // E8M0 127 = 2^0 in every byte: unit block scales
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bb), "v"(aa), "v"(one));
+    return c;
+}
+// A 32-B MX operand = the 16-B fragments of two k-steps, read by compiler-tracked LDS loads so that the register allocator
+// defines the two halves of the 8-register tuple in place (inline-asm ds_reads into 4-register values cost a copy per
+// operand: 48 VGPRs in the 256 x 256 kernel).  The caller fences the region with sched_barrier(0) on both sides.
+__device__ __forceinline__ i32x8 lds_pair(uint32_t addr_lo, uint32_t addr_hi) {
+    typedef const __attribute__((address_space(3))) u32x4* lp;
+    const u32x4 lo = *(lp)(addr_lo), hi = *(lp)(addr_hi);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+}
 __device__ __forceinline__ f32x16 mfma_mx(const u32x4& b0, const u32x4& b1, const u32x4& a0, const u32x4& a1, f32x16 c) {
     const i32x8 bb = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
     const i32x8 aa = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     // Two forms of the same K loop (identical schedule, waits and results).  bf16: the lean form.  fp8 (MX): the first form --
     // its 32-byte MFMA operands cost a register copy per fragment pair, the kernel sits at 256 VGPRs, and the lean form's
     // loop-invariant address registers tip it into scratch spills (VMEM traffic that also breaks the counted vmcnt waits).
-    if constexpr (!FP8) {
+    if constexpr (SPRC_FP8_LEAN || !FP8) {
         // ---- K loop, second form (same schedule, leaner instruction stream).  The s_memtime stamps of the first form showed an
         // NC interval taking 500-600 cycles to ISSUE 12 ds_read_b128 + 3 loads: the body carried ~20 branches per K-tile on
         // runtime flags (last tile? pieces left? which group?), per-read address arithmetic and a VGPR -> readfirstlane -> M0
@@ -688,7 +707,9 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             addr_a[x] = lds0 + (wr * TM * 32 + r32) * KTB + (c0 ^ (uint32_t)(x << 5));
             addr_b[x] = lds0 + B_BASE + (wc * TN * 32 + r32) * KTB + (c0 ^ (uint32_t)(x << 5));
         }
+        constexpr bool MX = FP8 && SPRC_FP8_MX;
         u32x4 fa[2][TM], fb[2][TN];
+        i32x8 fa8[TM], fb8[TN];                                 // MX: both k-steps of a cluster in one 8-register operand
         const bool pf_resid = p.resid != nullptr && !(p.debug & 1024);
         const float* pf_addr[4];
         uint32_t pf_sink = 0;
@@ -700,9 +721,11 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
                 pf_addr[i] = p.resid + prow * p.ldr + min(col, p.N - 1);
             }
         }
-        auto barrier = [&]() {
+        auto barrier = [&]() {                                  // nothing -- MFMAs included -- is scheduled across it
             asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::: "memory");
         };
 
@@ -719,6 +742,17 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         // fragments of k-steps 2h, 2h+1 of the K-tile in the stage of parity PAR: compile-time parity = pure immediates
         auto reads_c = [&](auto par_, auto h_) {
             constexpr int PAR = decltype(par_)::value, h = decltype(h_)::value;
+            if constexpr (MX) {
+                static_for<0, TM>([&](auto i) {
+                    constexpr uint32_t off = PAR * PAR_BYTES + decltype(i)::value * 32 * KTB;
+                    fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + off, addr_a[2 * h + 1] + off);
+                });
+                static_for<0, TN>([&](auto i) {
+                    constexpr uint32_t off = PAR * PAR_BYTES + decltype(i)::value * 32 * KTB;
+                    fb8[decltype(i)::value] = lds_pair(addr_b[2 * h] + off, addr_b[2 * h + 1] + off);
+                });
+                return;
+            }
             static_for<0, 2>([&](auto k_) {
                 constexpr int k = decltype(k_)::value;
                 static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<PAR * PAR_BYTES + decltype(i)::value * 32 * KTB>(addr_a[2 * h + k]); });
@@ -727,6 +761,17 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         };
         auto reads_r = [&](uint32_t par_bytes, auto h_) {       // run-time parity (the last K-tiles)
             constexpr int h = decltype(h_)::value;
+            if constexpr (MX) {
+                static_for<0, TM>([&](auto i) {
+                    constexpr uint32_t off = decltype(i)::value * 32 * KTB;
+                    fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + par_bytes + off, addr_a[2 * h + 1] + par_bytes + off);
+                });
+                static_for<0, TN>([&](auto i) {
+                    constexpr uint32_t off = decltype(i)::value * 32 * KTB;
+                    fb8[decltype(i)::value] = lds_pair(addr_b[2 * h] + par_bytes + off, addr_b[2 * h + 1] + par_bytes + off);
+                });
+                return;
+            }
             static_for<0, 2>([&](auto k_) {
                 constexpr int k = decltype(k_)::value;
                 const uint32_t an = addr_a[2 * h + k] + par_bytes, bn = addr_b[2 * h + k] + par_bytes;
@@ -741,7 +786,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             if constexpr (FP8 && SPRC_FP8_MX) {
                 static_for<0, 8>([&](auto x_) {
                     constexpr int x = decltype(x_)::value, mi = x >> 1, ni = x & 1;
-                    acc[mi][ni] = mfma_mx(fb[0][ni], fb[1][ni], fa[0][mi], fa[1][mi], acc[mi][ni]);
+                    acc[mi][ni] = mfma_mx8(fb8[ni], fa8[mi], acc[mi][ni]);
                     if constexpr (x == (SPRC_ANTI_LDPOS) / 2) { if (ld) load_piece(q_, I1{}, par_bytes, tile); }
                 });
             } else {
