@@ -53,9 +53,7 @@ struct GemmParams {
     int64_t split_stride;               // elements between the partial planes of consecutive K splits
     const float* w_scale; float a_scale;     // fp8 operands: acc * (a_scale * w_scale[n]) before the bias (null: no scaling)
     float out_scale;                    // fp8 output: value * out_scale before the conversion (1 / the consumer's dequantisation scale)
-    int debug;                          // SPRC_GEMM_DEBUG, timing experiments on the 256x256 kernel (results are WRONG with 1 / 2):
-                                        //   1 no global->LDS loads   2 no fragment reads   64 s_memtime stamp build (tools/gemm_stamp.py)
-                                        //   512 all four loads of an interval pair in the NC interval   1024 no residual prefetch
+    int debug;                          // SPRC_GEMM_DEBUG on the 256x256 kernel: 64 s_memtime stamp build (tools/gemm_stamp.py), 1024 no residual prefetch
 };
 
 __device__ __forceinline__ int64_t map_row_s(int shift, int stride, int off, int r) {
@@ -168,9 +166,6 @@ __device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x
 // SPRC_FP8_MX 0 falls back to two non-scaled 32x32x16 steps per fragment (bf16 rate).
 #ifndef SPRC_ANTI_LDPOS
 #define SPRC_ANTI_LDPOS 1          // the in-cluster load goes out after MFMA number LDPOS (0..15)
-#endif
-#ifndef SPRC_FP8_LEAN
-#define SPRC_FP8_LEAN 1            // 1: the fp8 instantiations of the 256 x 256 kernel use the lean K loop too
 #endif
 #ifndef SPRC_FP8_MX
 #define SPRC_FP8_MX 1
@@ -626,7 +621,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename std::conditional<FP8, fp8_t, bf16_t>::type T;
     constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
-    constexpr int BM = 256, BN = 256, STAGE_BYTES = (BM + BN) * KTB;
+    constexpr int BM = 256, BN = 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = __builtin_amdgcn_readfirstlane(wave / WN), wc = wave % WN;   // wr doubles as the phase group (SGPR: barriers under it)
     const int r32 = lane & 31, half = lane >> 5;
@@ -653,408 +648,252 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     };
     uint64_t ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // Two forms of the same K loop (identical schedule, waits and results).  bf16: the lean form.  fp8 (MX): the first form --
-    // its 32-byte MFMA operands cost a register copy per fragment pair, the kernel sits at 256 VGPRs, and the lean form's
-    // loop-invariant address registers tip it into scratch spills (VMEM traffic that also breaks the counted vmcnt waits).
-    if constexpr (SPRC_FP8_LEAN || !FP8) {
-        // ---- K loop, second form (same schedule, leaner instruction stream).  The s_memtime stamps of the first form showed an
-        // NC interval taking 500-600 cycles to ISSUE 12 ds_read_b128 + 3 loads: the body carried ~20 branches per K-tile on
-        // runtime flags (last tile? pieces left? which group?), per-read address arithmetic and a VGPR -> readfirstlane -> M0
-        // chain in front of every load.  Here the group (G), the stage parity and "is there a next / next-but-one K-tile" are
-        // template parameters of the iteration body: the steady-state loop has no branch but its back edge, fragment addresses
-        // are 8 loop-invariant VGPRs + immediates (stages interleaved as [A s0 | A s1 | B s0 | B s1] so a parity is a 32-KB
-        // immediate), and the LDS destination of a load is SGPR + immediate.
-        const int ltid = tid & 255;
-        const uint32_t wg_off = (uint32_t)__builtin_amdgcn_readfirstlane((wave & 3) * 1024);
-        const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of piece q in its operand
-        uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk from the tile's first row (K-tile 0)
-        const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
-        const char* a_base = p.A + a_row0 * p.lda_b;
-        const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
-        // everything up to the first load is exposed once per tile (s_memtime: 2-3.5 k cycles of a 75 k tile before this diet):
-        // offsets are < 2^32 by fits_u32(), rows of a tile < 2^8 -> 24-bit multiplies on the plain row map
-        const bool plain_a = p.a_shift < 0;
+    // ---- K loop.  The first form of this loop (round 1 / early round 2) followed the schedule above with run-time flags: its
+    // s_memtime stamps showed an NC interval taking 500-600 cycles to ISSUE 12 ds_read_b128 + 3 loads -- ~20 branches per
+    // K-tile (last tile? pieces left? which group?), per-read address arithmetic and a VGPR -> readfirstlane -> M0 chain in
+    // front of every load -- and a 640-cycle cluster (the in-cluster load queued behind the other group's).  This form keeps
+    // the schedule and the waits and strips the instruction stream: the steady state (K-tiles t+1 and t+2 exist) is unrolled
+    // by two so the stage parity is a compile-time constant, fragment addresses are 8 loop-invariant VGPRs + immediates
+    // (stages interleaved as [A s0 | A s1 | B s0 | B s1]: a parity is a 32-KB immediate), the LDS destination of a load is
+    // SGPR + immediate, and the only branches left are the group's three counted waits; the last (up to three) K-tiles run
+    // the same intervals on run-time flags.  NC issue 260 cycles, cluster 520, K-tile 3160 -> 2190 cycles (2048 = MFMA only).
+    // ONE code path for both groups on purpose: per-group copies of the tail made the allocator spill 2400 registers at the
+    // merge of the accumulator tuples.
+    // Tried on top and dropped: a PERSISTENT tile loop (one workgroup per CU; the next tile's setup and an L2 prefetch of its
+    // first K-tile issued before the epilogue): +1-3 % against the same code launched one workgroup per tile, but the state
+    // that then lives across the epilogue (kernel parameters, both tiles' descriptors) spills SGPRs into the steady loop
+    // (11 v_readlane per K-tile pair) and the kernel as a whole lost 4-9 % against this form.
+    const int ltid = tid & 255;
+    const uint32_t wg_off = (uint32_t)__builtin_amdgcn_readfirstlane((wave & 3) * 1024);
+    const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of piece q in its operand
+    uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk from the tile's first row (K-tile 0)
+    const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
+    const char* a_base = p.A + a_row0 * p.lda_b;
+    const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
+    // everything up to the first load is exposed once per tile (s_memtime: 2-3.5 k cycles of a 75 k tile before this diet):
+    // offsets are < 2^32 by fits_u32(), rows of a tile < 2^8 -> 24-bit multiplies on the plain row map
+    const bool plain_a = p.a_shift < 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = j * 256 + ltid, row = pc_row[q] + (c >> 3);
-                const int slot = (c & 7) ^ ((row >> 1) & 7);
-                uint32_t o;
-                if (q >= 2) {
-                    if (plain_a) o = __umul24((uint32_t)(min(m0 + row, p.M - 1) - m0), (uint32_t)p.lda_b);
-                    else o = (uint32_t)((map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b);
-                } else {
-                    o = __umul24((uint32_t)(min(n0 + row, p.N - 1) - n0), (uint32_t)p.ldw_b);
-                }
-                pc_off[q][j] = o + slot * 16;
-            }
-        }
-        const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a_base), rs_w = make_rsrc(w_base);
-        using std::integral_constant;
-        typedef integral_constant<int, 0> I0;
-        typedef integral_constant<int, 1> I1;
-        typedef integral_constant<int, 2> I2;
-        typedef integral_constant<int, 3> I3;
-
-
-        constexpr uint32_t PAR_BYTES = 256 * KTB, B_BASE = 2 * PAR_BYTES;   // [A s0 | A s1 | B s0 | B s1], 32 KB each
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-        const uint32_t c0 = (uint32_t)((half ^ ((r32 >> 1) & 7)) << 4);
-        uint32_t addr_a[4], addr_b[4];                          // per (h, k): k-step 2h + k of a K-tile
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            addr_a[x] = lds0 + (wr * TM * 32 + r32) * KTB + (c0 ^ (uint32_t)(x << 5));
-            addr_b[x] = lds0 + B_BASE + (wc * TN * 32 + r32) * KTB + (c0 ^ (uint32_t)(x << 5));
-        }
-        constexpr bool MX = FP8 && SPRC_FP8_MX;
-        u32x4 fa[2][TM], fb[2][TN];
-        i32x8 fa8[TM], fb8[TN];                                 // MX: both k-steps of a cluster in one 8-register operand
-        const bool pf_resid = p.resid != nullptr && !(p.debug & 1024);
-        const float* pf_addr[4];
-        uint32_t pf_sink = 0;
-        if (pf_resid) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int line = i * 64 + lane, row = m0 + wr * 128 + (line >> 1), col = n0 + wc * 64 + (line & 1) * 32;
-                const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, min(row, p.M - 1));
-                pf_addr[i] = p.resid + prow * p.ldr + min(col, p.N - 1);
-            }
-        }
-        auto barrier = [&]() {                                  // nothing -- MFMAs included -- is scheduled across it
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" ::: "memory");
-        };
-
-        // wave-uniform (SGPR) staging constants: LDS byte offset of piece q in parity 0 (+ this wave's 1-KB share of a 4-KB load)
-        uint32_t base_q[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) base_q[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((q >= 2 ? 0u : B_BASE) + pc_row[q] * KTB + wg_off));
-        // load j (of 2) of piece q (G0: B0 B1 | A2 A3, G1: B2 B3 | A0 A1) of K-tile `tile` into the stage of parity par_bytes / 32 KB
-        auto load_piece = [&](auto q_, auto j_, uint32_t par_bytes, int tile) {
-            constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
-            buffer_load_lds16(q >= 2 ? rs_a : rs_w, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
-        };
-        auto piece = [&](auto q_, uint32_t par_bytes, int tile) { load_piece(q_, I0{}, par_bytes, tile); load_piece(q_, I1{}, par_bytes, tile); };
-        // fragments of k-steps 2h, 2h+1 of the K-tile in the stage of parity PAR: compile-time parity = pure immediates
-        auto reads_c = [&](auto par_, auto h_) {
-            constexpr int PAR = decltype(par_)::value, h = decltype(h_)::value;
-            if constexpr (MX) {
-                static_for<0, TM>([&](auto i) {
-                    constexpr uint32_t off = PAR * PAR_BYTES + decltype(i)::value * 32 * KTB;
-                    fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + off, addr_a[2 * h + 1] + off);
-                });
-                static_for<0, TN>([&](auto i) {
-                    constexpr uint32_t off = PAR * PAR_BYTES + decltype(i)::value * 32 * KTB;
-                    fb8[decltype(i)::value] = lds_pair(addr_b[2 * h] + off, addr_b[2 * h + 1] + off);
-                });
-                return;
-            }
-            static_for<0, 2>([&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-                static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<PAR * PAR_BYTES + decltype(i)::value * 32 * KTB>(addr_a[2 * h + k]); });
-                static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<PAR * PAR_BYTES + decltype(i)::value * 32 * KTB>(addr_b[2 * h + k]); });
-            });
-        };
-        auto reads_r = [&](uint32_t par_bytes, auto h_) {       // run-time parity (the last K-tiles)
-            constexpr int h = decltype(h_)::value;
-            if constexpr (MX) {
-                static_for<0, TM>([&](auto i) {
-                    constexpr uint32_t off = decltype(i)::value * 32 * KTB;
-                    fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + par_bytes + off, addr_a[2 * h + 1] + par_bytes + off);
-                });
-                static_for<0, TN>([&](auto i) {
-                    constexpr uint32_t off = decltype(i)::value * 32 * KTB;
-                    fb8[decltype(i)::value] = lds_pair(addr_b[2 * h] + par_bytes + off, addr_b[2 * h + 1] + par_bytes + off);
-                });
-                return;
-            }
-            static_for<0, 2>([&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-                const uint32_t an = addr_a[2 * h + k] + par_bytes, bn = addr_b[2 * h + k] + par_bytes;
-                static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(an); });
-                static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(bn); });
-            });
-        };
-        // 16 MFMAs (k-steps 2h, 2h+1 of the 128 x 64 wave tile); the second load of piece q goes out after MFMA number
-        // SPRC_ANTI_LDPOS (`ld`: a compile-time true in the steady state, a run-time flag in the last K-tiles)
-        auto cluster = [&](auto q_, uint32_t par_bytes, auto ld, int tile) {
-            __builtin_amdgcn_s_setprio(1);
-            if constexpr (FP8 && SPRC_FP8_MX) {
-                static_for<0, 8>([&](auto x_) {
-                    constexpr int x = decltype(x_)::value, mi = x >> 1, ni = x & 1;
-                    acc[mi][ni] = mfma_mx8(fb8[ni], fa8[mi], acc[mi][ni]);
-                    if constexpr (x == (SPRC_ANTI_LDPOS) / 2) { if (ld) load_piece(q_, I1{}, par_bytes, tile); }
-                });
+        for (int j = 0; j < 2; ++j) {
+            const int c = j * 256 + ltid, row = pc_row[q] + (c >> 3);
+            const int slot = (c & 7) ^ ((row >> 1) & 7);
+            uint32_t o;
+            if (q >= 2) {
+                if (plain_a) o = __umul24((uint32_t)(min(m0 + row, p.M - 1) - m0), (uint32_t)p.lda_b);
+                else o = (uint32_t)((map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b);
             } else {
-                static_for<0, 16>([&](auto x_) {
-                    constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
-                    acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
-                    if constexpr (x == (SPRC_ANTI_LDPOS)) { if (ld) load_piece(q_, I1{}, par_bytes, tile); }
-                });
+                o = __umul24((uint32_t)(min(n0 + row, p.N - 1) - n0), (uint32_t)p.ldw_b);
             }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto stamp = [&](auto i_, int t) {
-            if constexpr (STAMP) {
-                if (t == 8 && ((p.ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
-            }
-        };
-        // NC(t,1) stages K-tile t+1 (G0) or t+2 (G1): tile index and stage parity of that piece pair
-        const uint32_t p2_bytes[2] = {wr ? 0u : PAR_BYTES, wr ? PAR_BYTES : 0u};      // indexed by the parity of t
-        // steady state: K-tiles t+1 and t+2 exist, parity of t known at compile time -> no branch but the group's waits
-        auto steady = [&](auto par_, int t) {
-            constexpr int PAR = decltype(par_)::value;
-            constexpr uint32_t pn = (PAR ^ 1) * PAR_BYTES;
-            const uint32_t p2 = p2_bytes[PAR];
-            const int t_p2 = t + 1 + wr;
-            stamp(integral_constant<int, 0>{}, t);
-            reads_c(par_, I0{});                                // NC(t,0)
-            piece(I0{}, pn, t + 1);
-            load_piece(I1{}, I0{}, pn, t + 1);
-            stamp(integral_constant<int, 1>{}, t);
-            wait_lgkmcnt<0>();
-            if (wr == 0) wait_vmcnt<3>();                       // A2 A3 of t landed (G1 reads them in the next interval)
-            stamp(integral_constant<int, 2>{}, t);
-            barrier();
-            stamp(integral_constant<int, 3>{}, t);
-            cluster(I1{}, pn, std::true_type{}, t + 1);         // C(t,0)
-            stamp(integral_constant<int, 4>{}, t);
-            barrier();
-            stamp(integral_constant<int, 5>{}, t);
-            reads_c(par_, I1{});                                // NC(t,1)
-            piece(I2{}, p2, t_p2);
-            load_piece(I3{}, I0{}, p2, t_p2);
-            stamp(integral_constant<int, 6>{}, t);
-            wait_lgkmcnt<0>();
-            if (wr == 1) wait_vmcnt<3>();                       // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
-            stamp(integral_constant<int, 7>{}, t);
-            barrier();
-            stamp(integral_constant<int, 8>{}, t);
-            cluster(I3{}, p2, std::true_type{}, t_p2);          // C(t,1)
-            stamp(integral_constant<int, 9>{}, t);
-            if (wr == 0) wait_vmcnt<4>();                       // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
-            stamp(integral_constant<int, 10>{}, t);
-            barrier();
-            stamp(integral_constant<int, 11>{}, t);
-        };
-        // the last (up to three) K-tiles: the same interval structure on run-time flags
-        auto tail = [&](int t, bool n1, bool n2) {
-            const bool last = !n1;
-            const uint32_t pb = (uint32_t)(t & 1) * PAR_BYTES, pn = pb ^ PAR_BYTES;
-            const uint32_t p2 = wr ? pb : pn;
-            const int t_p2 = t + 1 + wr;
-            const bool has_p2 = wr ? n2 : n1;
-            reads_r(pb, I0{});                                  // NC(t,0)
-            if (n1) { piece(I0{}, pn, t + 1); load_piece(I1{}, I0{}, pn, t + 1); }
-            wait_lgkmcnt<0>();
-            if (wr == 0) { if (n1) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
-            if (last && pf_resid) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_addr[i]) : "memory");
-            }
-            barrier();
-            cluster(I1{}, pn, n1, t + 1);                       // C(t,0)
-            barrier();
-            reads_r(pb, I1{});                                  // NC(t,1)
-            if (has_p2) { piece(I2{}, p2, t_p2); load_piece(I3{}, I0{}, p2, t_p2); }
-            wait_lgkmcnt<0>();
-            if (wr == 1 && !(last && pf_resid)) { if (n2) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
-            barrier();
-            cluster(I3{}, p2, has_p2, t_p2);                    // C(t,1)
-            if (wr == 0 && !(last && pf_resid)) { if (n1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
-            barrier();
-        };
-        // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
-        // flight, G1 one interval behind
-        if constexpr (STAMP) pro_ts[0] = __builtin_amdgcn_s_memtime();
-        static_for<0, 4>([&](auto q_) { piece(q_, 0u, 0); });
-        if constexpr (STAMP) pro_ts[1] = __builtin_amdgcn_s_memtime();
-        if (wr == 1 && nt > 1) { piece(I2{}, PAR_BYTES, 1); piece(I3{}, PAR_BYTES, 1); }
-        asm volatile("" ::: "memory");
-        zero_acc();                                         // 128 v_mov under the first loads' latency
-        asm volatile("" ::: "memory");
-        if (wr == 1 && nt > 1) wait_vmcnt<4>();
-        else wait_vmcnt<0>();
-        if constexpr (STAMP) pro_ts[2] = __builtin_amdgcn_s_memtime();
-        barrier();
-        if (wr == 1) barrier();
-        if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
-        {
-            int t = 0;
-            for (; t + 3 < nt; t += 2) {
-                steady(I0{}, t);
-                steady(I1{}, t + 1);
-            }
-            for (; t < nt; ++t) tail(t, t + 1 < nt, t + 2 < nt);
+            pc_off[q][j] = o + slot * 16;
         }
-        if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
-        if (pf_resid) {
-            wait_vmcnt<0>();                                    // the throw-away loads have written their register
-            asm volatile("" :: "v"(pf_sink));
-        }
-    } else {
-        zero_acc();
-        // piece q of this group: q = 0, 1 issued in NC(t,0), q = 2, 3 in NC(t,1):  G0: B0 B1 | A2 A3    G1: B2 B3 | A0 A1
-        // (K-tile t+1, except G1's A0 A1 which already belong to K-tile t+2)
-        const int ltid = tid & 255, wg = wave & 3;
-        const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of the piece in its operand
-        const bool pc_is_a[4] = {false, false, true, true};
-        uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk from the tile's first row (K-tile 0)
-        uint32_t pc_dst[4];                                     // LDS byte offset inside a stage (wave-uniform)
-        __amdgpu_buffer_rsrc_t pc_rsrc[4];                      // raw buffer over A or W: SGPR base + 32-bit offsets, no per-load VALU
-        const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
-        const char* a_base = p.A + a_row0 * p.lda_b;
-        const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = j * 256 + ltid, row = pc_row[q] + (c >> 3);
-                const int slot = (c & 7) ^ ((row >> 1) & 7);
-                const int64_t oa = (map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b;
-                const int64_t ow = (int64_t)(min(n0 + row, p.N - 1) - n0) * p.ldw_b;
-                pc_off[q][j] = (uint32_t)(pc_is_a[q] ? oa : ow) + slot * 16;
-            }
-            pc_dst[q] = ((pc_is_a[q] ? 0 : BM) + pc_row[q]) * KTB + wg * 1024;
-            pc_rsrc[q] = make_rsrc(pc_is_a[q] ? a_base : w_base);
-        }
-        auto load_piece = [&](auto q_, auto j_, int tile) {     // j-th load (of 2) of piece q of K-tile `tile`
-            constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
-            char* dst = smem + (tile & 1) * STAGE_BYTES + pc_dst[q] + j * 4096;
-            buffer_load_lds16(pc_rsrc[q], dst, pc_off[q][j], tile * KTB);
-        };
-        using std::integral_constant;
-        typedef integral_constant<int, 0> I0;
-        typedef integral_constant<int, 1> I1;
-        typedef integral_constant<int, 2> I2;
-        typedef integral_constant<int, 3> I3;
-        auto piece = [&](auto q_, int tile) { load_piece(q_, I0{}, tile); load_piece(q_, I1{}, tile); };
+    }
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(a_base), rs_w = make_rsrc(w_base);
+    using std::integral_constant;
+    typedef integral_constant<int, 0> I0;
+    typedef integral_constant<int, 1> I1;
+    typedef integral_constant<int, 2> I2;
+    typedef integral_constant<int, 3> I3;
 
 
-        const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-        const uint32_t c0 = (uint32_t)((half ^ ((r32 >> 1) & 7)) << 4);
-        const uint32_t a_off = lds0 + (wr * TM * 32 + r32) * KTB, b_off = lds0 + BM * KTB + (wc * TN * 32 + r32) * KTB;
-        u32x4 fa[2][TM], fb[2][TN];
-        auto reads = [&](int t, int h) {                        // fragments of K-tile t, k-steps 2h and 2h+1
-            const uint32_t so = (t & 1) * STAGE_BYTES;
-            static_for<0, 2>([&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-                const uint32_t cn = c0 ^ ((2 * h + k) << 5), an = a_off + so + cn, bn = b_off + so + cn;
-                static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(an); });
-                static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(bn); });
+    constexpr uint32_t PAR_BYTES = 256 * KTB, B_BASE = 2 * PAR_BYTES;   // [A s0 | A s1 | B s0 | B s1], 32 KB each
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
+    const uint32_t c0 = (uint32_t)((half ^ ((r32 >> 1) & 7)) << 4);
+    uint32_t addr_a[4], addr_b[4];                          // per (h, k): k-step 2h + k of a K-tile
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        addr_a[x] = lds0 + (wr * TM * 32 + r32) * KTB + (c0 ^ (uint32_t)(x << 5));
+        addr_b[x] = lds0 + B_BASE + (wc * TN * 32 + r32) * KTB + (c0 ^ (uint32_t)(x << 5));
+    }
+    constexpr bool MX = FP8 && SPRC_FP8_MX;
+    u32x4 fa[2][TM], fb[2][TN];
+    i32x8 fa8[TM], fb8[TN];                                 // MX: both k-steps of a cluster in one 8-register operand
+    const bool pf_resid = p.resid != nullptr && !(p.debug & 1024);
+    const float* pf_addr[4];
+    uint32_t pf_sink = 0;
+    if (pf_resid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int line = i * 64 + lane, row = m0 + wr * 128 + (line >> 1), col = n0 + wc * 64 + (line & 1) * 32;
+            const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, min(row, p.M - 1));
+            pf_addr[i] = p.resid + prow * p.ldr + min(col, p.N - 1);
+        }
+    }
+    auto barrier = [&]() {                                  // nothing -- MFMAs included -- is scheduled across it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
+
+    // wave-uniform (SGPR) staging constants: LDS byte offset of piece q in parity 0 (+ this wave's 1-KB share of a 4-KB load)
+    uint32_t base_q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) base_q[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((q >= 2 ? 0u : B_BASE) + pc_row[q] * KTB + wg_off));
+    // load j (of 2) of piece q (G0: B0 B1 | A2 A3, G1: B2 B3 | A0 A1) of K-tile `tile` into the stage of parity par_bytes / 32 KB
+    auto load_piece = [&](auto q_, auto j_, uint32_t par_bytes, int tile) {
+        constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
+        buffer_load_lds16(q >= 2 ? rs_a : rs_w, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
+    };
+    auto piece = [&](auto q_, uint32_t par_bytes, int tile) { load_piece(q_, I0{}, par_bytes, tile); load_piece(q_, I1{}, par_bytes, tile); };
+    // fragments of k-steps 2h, 2h+1 of the K-tile in the stage of parity PAR: compile-time parity = pure immediates
+    auto reads_c = [&](auto par_, auto h_) {
+        constexpr int PAR = decltype(par_)::value, h = decltype(h_)::value;
+        if constexpr (MX) {
+            static_for<0, TM>([&](auto i) {
+                constexpr uint32_t off = PAR * PAR_BYTES + decltype(i)::value * 32 * KTB;
+                fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + off, addr_a[2 * h + 1] + off);
             });
-        };
-        // 16 MFMAs: k-steps 2h, 2h+1 of the 128 x 64 wave tile; when `tile` >= 0 the SECOND load of piece q goes out mid-cluster
-        auto cluster = [&](auto q_, int tile) {
-            __builtin_amdgcn_s_setprio(1);
-            if constexpr (FP8 && SPRC_FP8_MX) {                  // 8 MX MFMAs (K = 64 each): the cluster lasts as long as 16 bf16 ones
-                static_for<0, 8>([&](auto x_) {
-                    constexpr int x = decltype(x_)::value, mi = x >> 1, ni = x & 1;
-                    acc[mi][ni] = mfma_mx(fb[0][ni], fb[1][ni], fa[0][mi], fa[1][mi], acc[mi][ni]);
-                    if constexpr (x == 3) { if (tile >= 0) load_piece(q_, I1{}, tile); }
-                });
-            } else {
-                static_for<0, 16>([&](auto x_) {
-                    constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
-                    acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
-                    if constexpr (x == 7) { if (tile >= 0) load_piece(q_, I1{}, tile); }
-                });
-            }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto wait_vm = [&](bool newer) {                        // leave the newest two pieces (4 loads) in flight, if issued
-            if (newer) wait_vmcnt<4>();
-            else wait_vmcnt<0>();
-        };
-        auto barrier = [&]() {
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        };
-
-        // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
-        // flight, G1 one interval behind
-        static_for<0, 4>([&](auto q_) { piece(q_, 0); });
-        if (wr == 1 && nt > 1) { piece(I2{}, 1); piece(I3{}, 1); wait_vmcnt<4>(); }
-        else wait_vmcnt<0>();
+            static_for<0, TN>([&](auto i) {
+                constexpr uint32_t off = PAR * PAR_BYTES + decltype(i)::value * 32 * KTB;
+                fb8[decltype(i)::value] = lds_pair(addr_b[2 * h] + off, addr_b[2 * h + 1] + off);
+            });
+            return;
+        }
+        static_for<0, 2>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<PAR * PAR_BYTES + decltype(i)::value * 32 * KTB>(addr_a[2 * h + k]); });
+            static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<PAR * PAR_BYTES + decltype(i)::value * 32 * KTB>(addr_b[2 * h + k]); });
+        });
+    };
+    auto reads_r = [&](uint32_t par_bytes, auto h_) {       // run-time parity (the last K-tiles)
+        constexpr int h = decltype(h_)::value;
+        if constexpr (MX) {
+            static_for<0, TM>([&](auto i) {
+                constexpr uint32_t off = decltype(i)::value * 32 * KTB;
+                fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + par_bytes + off, addr_a[2 * h + 1] + par_bytes + off);
+            });
+            static_for<0, TN>([&](auto i) {
+                constexpr uint32_t off = decltype(i)::value * 32 * KTB;
+                fb8[decltype(i)::value] = lds_pair(addr_b[2 * h] + par_bytes + off, addr_b[2 * h + 1] + par_bytes + off);
+            });
+            return;
+        }
+        static_for<0, 2>([&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            const uint32_t an = addr_a[2 * h + k] + par_bytes, bn = addr_b[2 * h + k] + par_bytes;
+            static_for<0, TM>([&](auto i) { fa[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(an); });
+            static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<decltype(i)::value * 32 * KTB>(bn); });
+        });
+    };
+    // 16 MFMAs (k-steps 2h, 2h+1 of the 128 x 64 wave tile); the second load of piece q goes out after MFMA number
+    // SPRC_ANTI_LDPOS (`ld`: a compile-time true in the steady state, a run-time flag in the last K-tiles)
+    auto cluster = [&](auto q_, uint32_t par_bytes, auto ld, int tile) {
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (FP8 && SPRC_FP8_MX) {
+            static_for<0, 8>([&](auto x_) {
+                constexpr int x = decltype(x_)::value, mi = x >> 1, ni = x & 1;
+                acc[mi][ni] = mfma_mx8(fb8[ni], fa8[mi], acc[mi][ni]);
+                if constexpr (x == (SPRC_ANTI_LDPOS) / 2) { if (ld) load_piece(q_, I1{}, par_bytes, tile); }
+            });
+        } else {
+            static_for<0, 16>([&](auto x_) {
+                constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
+                acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
+                if constexpr (x == (SPRC_ANTI_LDPOS)) { if (ld) load_piece(q_, I1{}, par_bytes, tile); }
+            });
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto stamp = [&](auto i_, int t) {
+        if constexpr (STAMP) {
+            if (t == 8 && ((p.ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
+        }
+    };
+    // NC(t,1) stages K-tile t+1 (G0) or t+2 (G1): tile index and stage parity of that piece pair
+    const uint32_t p2_bytes[2] = {wr ? 0u : PAR_BYTES, wr ? PAR_BYTES : 0u};      // indexed by the parity of t
+    // steady state: K-tiles t+1 and t+2 exist, parity of t known at compile time -> no branch but the group's waits
+    auto steady = [&](auto par_, int t) {
+        constexpr int PAR = decltype(par_)::value;
+        constexpr uint32_t pn = (PAR ^ 1) * PAR_BYTES;
+        const uint32_t p2 = p2_bytes[PAR];
+        const int t_p2 = t + 1 + wr;
+        stamp(integral_constant<int, 0>{}, t);
+        reads_c(par_, I0{});                                // NC(t,0)
+        piece(I0{}, pn, t + 1);
+        load_piece(I1{}, I0{}, pn, t + 1);
+        stamp(integral_constant<int, 1>{}, t);
+        wait_lgkmcnt<0>();
+        if (wr == 0) wait_vmcnt<3>();                       // A2 A3 of t landed (G1 reads them in the next interval)
+        stamp(integral_constant<int, 2>{}, t);
         barrier();
-        if (wr == 1) barrier();
-        if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
-        const bool dbg_noload = p.debug & 1, dbg_noread = p.debug & 2;
-        // 3 of an interval pair's 4 loads go out in the NC interval, the 4th after the 8th MFMA of the following cluster:
-        // NC (12 fragment reads + loads, ~600 cycles) was longer than the cluster (~530); A/B +2 % (debug bit 512 = all 4 in NC)
-        const bool split31 = !(p.debug & 512);
-        if (dbg_noread) { reads(0, 0); wait_lgkmcnt<0>(); }
-        // STAMP build (tools only): s_memtime at the phase boundaries of K-tile 8, written over p.resid by waves 0 and 4 of WG 0
-        auto stamp = [&](auto i_, int t) {
-            if constexpr (STAMP) {
-                if (t == 8 && ((p.ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
-            }
-        };
-        // Residual prefetch: one throw-away dword load per 128-B line of this wave's 128 x 64 fp32 residual block (4 per lane),
-        // issued in the LAST K-tile -- no staging load is outstanding or issued any more, so its vmcnt waits are dropped --
-        // so that the read half of the epilogue's HBM burst happens under the last MFMAs and the epilogue finds the lines in L2.
-        const bool pf_resid = p.resid != nullptr && !(p.debug & 1024);
-        const float* pf_addr[4];
-        uint32_t pf_sink = 0;
-        if (pf_resid) {
+        stamp(integral_constant<int, 3>{}, t);
+        cluster(I1{}, pn, std::true_type{}, t + 1);         // C(t,0)
+        stamp(integral_constant<int, 4>{}, t);
+        barrier();
+        stamp(integral_constant<int, 5>{}, t);
+        reads_c(par_, I1{});                                // NC(t,1)
+        piece(I2{}, p2, t_p2);
+        load_piece(I3{}, I0{}, p2, t_p2);
+        stamp(integral_constant<int, 6>{}, t);
+        wait_lgkmcnt<0>();
+        if (wr == 1) wait_vmcnt<3>();                       // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
+        stamp(integral_constant<int, 7>{}, t);
+        barrier();
+        stamp(integral_constant<int, 8>{}, t);
+        cluster(I3{}, p2, std::true_type{}, t_p2);          // C(t,1)
+        stamp(integral_constant<int, 9>{}, t);
+        if (wr == 0) wait_vmcnt<4>();                       // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
+        stamp(integral_constant<int, 10>{}, t);
+        barrier();
+        stamp(integral_constant<int, 11>{}, t);
+    };
+    // the last (up to three) K-tiles: the same interval structure on run-time flags
+    auto tail = [&](int t, bool n1, bool n2) {
+        const bool last = !n1;
+        const uint32_t pb = (uint32_t)(t & 1) * PAR_BYTES, pn = pb ^ PAR_BYTES;
+        const uint32_t p2 = wr ? pb : pn;
+        const int t_p2 = t + 1 + wr;
+        const bool has_p2 = wr ? n2 : n1;
+        reads_r(pb, I0{});                                  // NC(t,0)
+        if (n1) { piece(I0{}, pn, t + 1); load_piece(I1{}, I0{}, pn, t + 1); }
+        wait_lgkmcnt<0>();
+        if (wr == 0) { if (n1) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
+        if (last && pf_resid) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int line = i * 64 + lane, row = m0 + wr * 128 + (line >> 1), col = n0 + wc * 64 + (line & 1) * 32;
-                const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, min(row, p.M - 1));
-                pf_addr[i] = p.resid + prow * p.ldr + min(col, p.N - 1);
-            }
+            for (int i = 0; i < 4; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_addr[i]) : "memory");
         }
-        for (int t = 0; t < nt; ++t) {
-            const bool n1 = t + 1 < nt && !dbg_noload, n2 = t + 2 < nt && !dbg_noload;
-            const bool last = t + 1 == nt;
-            const int t_p2 = wr ? t + 2 : t + 1;                // K-tile of the pieces issued in NC(t,1)
-            const bool has_p2 = wr ? n2 : n1;
-            stamp(integral_constant<int, 0>{}, t);
-            if (!dbg_noread) reads(t, 0);                       // NC(t,0)
-            if (n1) { piece(I0{}, t + 1); load_piece(I1{}, I0{}, t + 1); if (!split31) load_piece(I1{}, I1{}, t + 1); }
-            stamp(integral_constant<int, 1>{}, t);
-            wait_lgkmcnt<0>();
-            if (wr == 0) {                                      // A2 A3 of t landed (G1 reads them in the next interval)
-                if (split31 && n1) wait_vmcnt<3>(); else wait_vm(n1);
-            }
-            if (last && pf_resid) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_addr[i]) : "memory");
-            }
-            stamp(integral_constant<int, 2>{}, t);
-            barrier();
-            stamp(integral_constant<int, 3>{}, t);
-            cluster(I1{}, split31 && n1 ? t + 1 : -1);          // C(t,0)
-            stamp(integral_constant<int, 4>{}, t);
-            barrier();
-            stamp(integral_constant<int, 5>{}, t);
-            if (!dbg_noread) reads(t, 1);                       // NC(t,1)
-            if (has_p2) { piece(I2{}, t_p2); load_piece(I3{}, I0{}, t_p2); if (!split31) load_piece(I3{}, I1{}, t_p2); }
-            stamp(integral_constant<int, 6>{}, t);
-            wait_lgkmcnt<0>();
-            if (wr == 1 && !(last && pf_resid)) {               // A0 A1 B2 B3 of t+1 landed; A0 A1 of t+2 may fly
-                if (split31 && n2) wait_vmcnt<3>(); else wait_vm(n2);
-            }
-            stamp(integral_constant<int, 7>{}, t);
-            barrier();
-            stamp(integral_constant<int, 8>{}, t);
-            cluster(I3{}, split31 && has_p2 ? t_p2 : -1);       // C(t,1)
-            stamp(integral_constant<int, 9>{}, t);
-            if (wr == 0 && !(last && pf_resid)) wait_vm(n1);    // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
-            stamp(integral_constant<int, 10>{}, t);
-            barrier();
-            stamp(integral_constant<int, 11>{}, t);
+        barrier();
+        cluster(I1{}, pn, n1, t + 1);                       // C(t,0)
+        barrier();
+        reads_r(pb, I1{});                                  // NC(t,1)
+        if (has_p2) { piece(I2{}, p2, t_p2); load_piece(I3{}, I0{}, p2, t_p2); }
+        wait_lgkmcnt<0>();
+        if (wr == 1 && !(last && pf_resid)) { if (n2) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
+        barrier();
+        cluster(I3{}, p2, has_p2, t_p2);                    // C(t,1)
+        if (wr == 0 && !(last && pf_resid)) { if (n1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+        barrier();
+    };
+    // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
+    // flight, G1 one interval behind
+    if constexpr (STAMP) pro_ts[0] = __builtin_amdgcn_s_memtime();
+    static_for<0, 4>([&](auto q_) { piece(q_, 0u, 0); });
+    if constexpr (STAMP) pro_ts[1] = __builtin_amdgcn_s_memtime();
+    if (wr == 1 && nt > 1) { piece(I2{}, PAR_BYTES, 1); piece(I3{}, PAR_BYTES, 1); }
+    asm volatile("" ::: "memory");
+    zero_acc();                                         // 128 v_mov under the first loads' latency
+    asm volatile("" ::: "memory");
+    if (wr == 1 && nt > 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    if constexpr (STAMP) pro_ts[2] = __builtin_amdgcn_s_memtime();
+    barrier();
+    if (wr == 1) barrier();
+    if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
+    {
+        int t = 0;
+        for (; t + 3 < nt; t += 2) {
+            steady(I0{}, t);
+            steady(I1{}, t + 1);
         }
-        if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
-        if (pf_resid) {
-            wait_vmcnt<0>();                                    // the throw-away loads have written their register
-            asm volatile("" :: "v"(pf_sink));
-        }
+        for (; t < nt; ++t) tail(t, t + 1 < nt, t + 2 < nt);
+    }
+    if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
+    if (pf_resid) {
+        wait_vmcnt<0>();                                    // the throw-away loads have written their register
+        asm volatile("" :: "v"(pf_sink));
     }
     if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
