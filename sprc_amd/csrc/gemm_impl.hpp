@@ -140,6 +140,10 @@ __device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
     return v;
 }
 template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void wait_lgkmcnt() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);       // keep the MFMAs below the wait (guide rule 18)
@@ -428,9 +432,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
     }
 }
 
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN>
+// NS = LDS stages.  2: K-tile t+1 is fetched while t is multiplied, one vmcnt(0) + barrier per K-tile -- right when several
+// workgroups share a CU and cover each other's waits.  4: a ring three K-tiles deep with counted waits, for the launches that
+// cannot even give every CU a workgroup (remainder rows, the small Q-Former products): there a K-tile cost a full memory
+// round trip (~1.5 k cycles for 4 MFMAs; the 128-row ViT remainders 20 us per launch).
+template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int NS = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(NS == 2 || (NS == 4 && sizeof(T) <= 2), "stages: 2, or a ring of 4 for 1- and 2-byte operands");
     constexpr int KT_BYTES = 128;
     constexpr int NT = 64 * WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int STAGE_BYTES = (BM + BN) * KT_BYTES;
@@ -492,10 +501,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
                         ((uintptr_t)p.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)p.bias % 16 == 0) && ((uintptr_t)p.resid % 16 == 0);
 
-    if (nt > 0) {                                               // K-tile 0
-        char* dst0 = smem + wave * 1024;
-        static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst0, kbase); });
-    }
+    static_for<0, NS - 1>([&](auto d_) {                        // K-tiles 0 .. NS-2
+        constexpr int d = decltype(d_)::value;
+        if (d < nt) {
+            char* dst0 = smem + d * STAGE_BYTES + wave * 1024;
+            static_for<0, LA + LB>([&](auto j_) { stage_one(j_, dst0, kbase + (int64_t)d * KT_BYTES); });
+        }
+    });
 
     {
         f32x16 acc[TM][TN];
@@ -508,12 +520,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
 
         // ---- main loop: K-tile t is in buffer t&1 (tile 0 was issued before we got here) ----
         for (int t = 0; t < nt; ++t) {
-            __syncthreads();                 // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free again
-            const bool more = t + 1 < nt;
-            const int64_t ko = kbase + (int64_t)(t + 1) * KT_BYTES;
+            if constexpr (NS == 2) {
+                __syncthreads();             // tile t landed (vmcnt(0) + barrier); buffer (t+1)&1 is free again
+            } else {                         // ring: K-tiles up to t + NS - 2 are in flight, tile t has to have landed
+                constexpr int L = LA + LB;
+                const int later = min(NS - 2, nt - 1 - t);
+                if (later >= 2) wait_vmcnt<2 * L>();
+                else if (later == 1) wait_vmcnt<L>();
+                else wait_vmcnt<0>();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();    // ... in every wave; and everyone is done reading stage (t - 1) % NS, refilled below
+                asm volatile("" ::: "memory");
+            }
+            const bool more = t + NS - 1 < nt;
+            const int64_t ko = kbase + (int64_t)(t + NS - 1) * KT_BYTES;
             if constexpr (sizeof(T) <= 2) {
-                char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
-                const uint32_t so = lds0 + (t & 1) * STAGE_BYTES;
+                char* dst = smem + ((t + NS - 1) & (NS - 1)) * STAGE_BYTES + wave * 1024;
+                const uint32_t so = lds0 + (t & (NS - 1)) * STAGE_BYTES;
                 auto issue = [&](auto kk_) {
                     constexpr int kk = decltype(kk_)::value;
                     if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
@@ -589,10 +612,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Anti-phase bf16 variant of the 256 x 256 tile (the schedule idea of the guide's 8-phase template, T3/T4/T5).
@@ -956,13 +975,13 @@ static void optin_lds(K kern, int bytes, bool (&done)[MAX_DEVICES]) {
     }
 }
 
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT>
+template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT, int NS = 2>
 static int launch_cfg(GemmParams p, hipStream_t st) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = 2 * (BM + BN) * 128;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = NS * (BM + BN) * 128;
     // (A persistent variant -- grid = CUs x residency with the next tile's first K-tile prefetched before the epilogue --
     // measured equal to one workgroup per tile on MI355X while costing ~45 VGPRs: all tiles take the same time, so the
     // CUs stay in lockstep and the output-write bursts still coincide.  Removed.)
-    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN>;
+    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN, NS>;
     static bool attr_set[MAX_DEVICES] = {false};
     optin_lds(kern, LDS, attr_set);
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -1073,7 +1092,9 @@ static int launch(const GemmParams& p, hipStream_t st) {
                     GemmParams ps = pt;
                     ps.C = p.scratch; ps.ldc = p.N; ps.bias = nullptr; ps.resid = nullptr; ps.ldr = 0; ps.w_scale = nullptr;
                     ps.ksplit = S; ps.split_stride = (int64_t)rem * p.N;
-                    const int rs = launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 2>(ps, st);
+                    static const int ring = env_int("SPRC_GEMM_RING", 1);   // a handful of workgroups: ring of 4 stages (0: two stages, A/B)
+                    const int rs = ring ? launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 1, 4>(ps, st)
+                                        : launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 2>(ps, st);
                     if (rs != SPRC_OK) return rs;
                     const int64_t n = (int64_t)rem * (p.N / 4);
                     hipLaunchKernelGGL((splitk_reduce_kernel<OutT, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
@@ -1083,7 +1104,9 @@ static int launch(const GemmParams& p, hipStream_t st) {
                     return SPRC_OK;
                 }
                 if constexpr (sizeof(T) == 2 && !MAX32) {
-                    if (((rem + 127) / 128) * tn128 <= ncu) return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(pt, st);
+                    static const int ring = env_int("SPRC_GEMM_RING", 1);
+                    if (((rem + 127) / 128) * tn128 <= ncu)
+                        return ring ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4>(pt, st) : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(pt, st);
                 }
                 return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(pt, st);
             }
@@ -1101,7 +1124,13 @@ static int launch(const GemmParams& p, hipStream_t st) {
     }
     if (cfg == 4 || cfg == 10 || cfg == 14) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
     if constexpr (sizeof(T) == 2 && !MAX32) {
-        if (cfg == 1) return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(p, st);     // 64 x 64 tile, 32 KB LDS: small latency-bound products
+        if (cfg == 1) {                                     // 64 x 64 tile: small latency-bound products; ring of 4 stages (64 KB) or 2 (32 KB)
+            // (the ring's 64 KB leave two workgroups per CU: only for grids that fit then -- 768 workgroups ran 5 % slower on it)
+            static const int ring = env_int("SPRC_GEMM_RING", 1);
+            const int64_t nwg64 = (p.dual ? 2 : 1) * (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+            return ring && nwg64 <= 2 * num_cus() ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4>(p, st)
+                                                  : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(p, st);
+        }
     }
     return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(p, st);
 }
