@@ -74,6 +74,22 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     float* sM = reinterpret_cast<float*>(sV + (size_t)DHP * VROW);
 
     const int dh = p.dh;
+    const int nqt = (p.Tq + 31) >> 5;
+    // Q^T fragment (B operand) of query tile qt: lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8].  The wave's FIRST tile is
+    // fetched here, before the K / V staging, so its memory round trip runs under the staging instead of after the barrier
+    // (the Q-Former launches are a few tiles per workgroup: that round trip was a fifth of their time).
+    auto load_q = [&](int qt, bf16x8 (&qf)[KS]) {
+        const int qrow = min(qt * 32 + r32, p.Tq - 1);
+        const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + half * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(qptr + (d0 < dh ? d0 : 0) * 2);
+            qf[ks] = __builtin_bit_cast(bf16x8, d0 < dh ? v : u32x4{0u, 0u, 0u, 0u});
+        }
+    };
+    bf16x8 qf[KS];
+    load_q(min(wave, nqt - 1), qf);
 
     // ---- stage K (row-major, zero padded) and V transposed (VT[d][key], two keys per 32-bit write).  Global loads are
     // issued in batches of UNR independent requests per thread before any LDS write, so a batch costs one memory
@@ -83,10 +99,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     for (int it0 = tid; it0 < nK; it0 += NTH * UNR) {
         u32x4 val[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int it = it0 + u * NTH, t = it / CPR, c = it % CPR;
-            val[u] = u32x4{0u, 0u, 0u, 0u};
-            if (it < nK && t < p.Tk && c * 8 < dh) val[u] = *reinterpret_cast<const u32x4*>(kv_token(p, p.k, p.ldk, p.k2, p.ldk2, b, h, t) + c * 16);
+        for (int u = 0; u < UNR; ++u) {             // branch-free: clamped address, the value masked afterwards (predicated loads
+            const int it = min(it0 + u * NTH, nK - 1), t = it / CPR, c = it % CPR;     // make hipcc drain the queue where they meet)
+            const bool ok = t < p.Tk && c * 8 < dh;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(kv_token(p, p.k, p.ldk, p.k2, p.ldk2, b, h, min(t, p.Tk - 1)) + (ok ? c : 0) * 16);
+            val[u] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -99,12 +116,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
         u32x4 va[UNR / 2], vb[UNR / 2];
 #pragma unroll
         for (int u = 0; u < UNR / 2; ++u) {
-            const int it = it0 + u * NTH, kp = it % (Tkp / 2), c = it / (Tkp / 2), t0 = kp * 2;
-            va[u] = vb[u] = u32x4{0u, 0u, 0u, 0u};
-            if (it < nV && c * 8 < dh) {
-                if (t0 < p.Tk) va[u] = *reinterpret_cast<const u32x4*>(kv_token(p, p.v, p.ldv, p.v2, p.ldv2, b, h, t0) + c * 16);
-                if (t0 + 1 < p.Tk) vb[u] = *reinterpret_cast<const u32x4*>(kv_token(p, p.v, p.ldv, p.v2, p.ldv2, b, h, t0 + 1) + c * 16);
-            }
+            const int it = min(it0 + u * NTH, nV - 1), kp = it % (Tkp / 2), c = it / (Tkp / 2), t0 = kp * 2;
+            const bool okc = c * 8 < dh;
+            const int cc = okc ? c : 0;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(kv_token(p, p.v, p.ldv, p.v2, p.ldv2, b, h, min(t0, p.Tk - 1)) + cc * 16);
+            const u32x4 bq = *reinterpret_cast<const u32x4*>(kv_token(p, p.v, p.ldv, p.v2, p.ldv2, b, h, min(t0 + 1, p.Tk - 1)) + cc * 16);
+            va[u] = (okc && t0 < p.Tk) ? a : u32x4{0u, 0u, 0u, 0u};
+            vb[u] = (okc && t0 + 1 < p.Tk) ? bq : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < UNR / 2; ++u) {
@@ -128,20 +146,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     __syncthreads();
 
     const float sc = p.scale * LOG2E;
-    const int nqt = (p.Tq + 31) >> 5, nkt = Tkp >> 5;
+    const int nkt = Tkp >> 5;
     const bool plain_tail = (p.Tk & 31) == 0;
     for (int qt = wave; qt < nqt; qt += NW) {
-        // Q^T fragment (B operand): lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8]
-        const int qrow = min(qt * 32 + r32, p.Tq - 1);
-        const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
-        bf16x8 qf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 16 + half * 8;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (d0 < dh) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
-            qf[ks] = __builtin_bit_cast(bf16x8, val);
-        }
+        if (qt != wave) load_q(qt, qf);
         f32x16 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
