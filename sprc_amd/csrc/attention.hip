@@ -655,7 +655,7 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
         SPRC_REQUIRE(!two || (a->ldk2 % 8 == 0 && a->ldv2 % 8 == 0 && ((uintptr_t)a->k2 % 16) == 0 && ((uintptr_t)a->v2 % 16) == 0),
                      "sprc_attention(bf16): second key segment misaligned");
         const bool small = a->Tq <= 128;
-        // long query axes without a key mask (the ViT blocks): streaming kernel, five small workgroups per CU
+        // long query axes without a key mask (the ViT blocks): streaming kernel, four workgroups of three waves per CU (153 VGPRs)
         // (SPRC_ATTN_STREAM=0 keeps the resident-K/V kernel for A/B runs)
         static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
         if (stream && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {

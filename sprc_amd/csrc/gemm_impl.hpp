@@ -1112,7 +1112,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
             }
             cfg = cB <= cA ? 4 : 2;
             // a 128x128 grid that cannot even give every CU one workgroup is latency-bound (12-48 K-tiles on a fraction of the
-            // chip): 64x64 tiles (32 KB LDS, four workgroups per CU) spread it 4x wider.  Measured: 4096x768x768 17.6 -> 12.7 us,
+            // chip): 64x64 tiles (16 KB per LDS stage) spread it 4x wider.  Measured: 4096x768x768 17.6 -> 12.7 us,
             // 4096x768x3072 44.9 -> 37.6, the 128-row remainders of the ViT products 18.3 -> 11.4-12.2; grids above one
             // workgroup per CU (7456x768x768, 4096x2304x768) are equal or slower on 64x64 and keep 128x128.
             if (cfg == 2 && !MAX32 && sizeof(T) == 2 && mult * ((p.M + 127) / 128) * tn128 <= ncu) cfg = 1;
