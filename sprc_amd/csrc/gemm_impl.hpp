@@ -53,7 +53,7 @@ struct GemmParams {
     int64_t split_stride;               // elements between the partial planes of consecutive K splits
     const float* w_scale; float a_scale;     // fp8 operands: acc * (a_scale * w_scale[n]) before the bias (null: no scaling)
     float out_scale;                    // fp8 output: value * out_scale before the conversion (1 / the consumer's dequantisation scale)
-    int debug;                          // SPRC_GEMM_DEBUG on the 256x256 kernel: 64 s_memtime stamp build (tools/gemm_stamp.py), 1024 no residual prefetch
+    int debug;                          // SPRC_GEMM_DEBUG on the 256x256 kernel: 64 s_memtime stamp build (tools/gemm_stamp.py)
 };
 
 __device__ __forceinline__ int64_t map_row_s(int shift, int stride, int off, int r) {
@@ -728,17 +728,9 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     constexpr bool MX = FP8 && SPRC_FP8_MX;
     u32x4 fa[2][TM], fb[2][TN];
     i32x8 fa8[TM], fb8[TN];                                 // MX: both k-steps of a cluster in one 8-register operand
-    const bool pf_resid = p.resid != nullptr && !(p.debug & 1024);
-    const float* pf_addr[4];
-    uint32_t pf_sink = 0;
-    if (pf_resid) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int line = i * 64 + lane, row = m0 + wr * 128 + (line >> 1), col = n0 + wc * 64 + (line & 1) * 32;
-            const int64_t prow = map_row_s(p.c_shift, p.c_stride, p.c_off, min(row, p.M - 1));
-            pf_addr[i] = p.resid + prow * p.ldr + min(col, p.N - 1);
-        }
-    }
+    // (A residual PREFETCH -- throw-away dword loads over the tile's residual lines in the last K-tile -- paid while the epilogue
+    // fetched each 32-row block only when it reached it; with the epilogue's own two-blocks-ahead loads it COSTS 2-7 % of the
+    // fp32 + residual products: a dword load per 128-B line is 64 lines per wave instruction.  Removed.)
     auto barrier = [&]() {                                  // nothing -- MFMAs included -- is scheduled across it
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -861,7 +853,6 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     };
     // the last (up to three) K-tiles: the same interval structure on run-time flags
     auto tail = [&](int t, bool n1, bool n2) {
-        const bool last = !n1;
         const uint32_t pb = (uint32_t)(t & 1) * PAR_BYTES, pn = pb ^ PAR_BYTES;
         const uint32_t p2 = wr ? pb : pn;
         const int t_p2 = t + 1 + wr;
@@ -870,20 +861,16 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         if (n1) { piece(I0{}, pn, t + 1); load_piece(I1{}, I0{}, pn, t + 1); }
         wait_lgkmcnt<0>();
         if (wr == 0) { if (n1) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
-        if (last && pf_resid) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_addr[i]) : "memory");
-        }
         barrier();
         cluster(I1{}, pn, n1, t + 1);                       // C(t,0)
         barrier();
         reads_r(pb, I1{});                                  // NC(t,1)
         if (has_p2) { piece(I2{}, p2, t_p2); load_piece(I3{}, I0{}, p2, t_p2); }
         wait_lgkmcnt<0>();
-        if (wr == 1 && !(last && pf_resid)) { if (n2) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
+        if (wr == 1) { if (n2) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
         barrier();
         cluster(I3{}, p2, has_p2, t_p2);                    // C(t,1)
-        if (wr == 0 && !(last && pf_resid)) { if (n1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+        if (wr == 0) { if (n1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
         barrier();
     };
     // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
@@ -910,10 +897,6 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         for (; t < nt; ++t) tail(t, t + 1 < nt, t + 2 < nt);
     }
     if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
-    if (pf_resid) {
-        wait_vmcnt<0>();                                    // the throw-away loads have written their register
-        asm volatile("" :: "v"(pf_sink));
-    }
     if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
     const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
                         ((uintptr_t)p.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)p.bias % 16 == 0) && ((uintptr_t)p.resid % 16 == 0);
