@@ -39,16 +39,18 @@ class TargetPad:
         return ImageOps.expand(image, border=(hp, vp, hp, vp), fill=0)
 
 
-def targetpad_transform(target_ratio: float, dim: int) -> Callable:
+class HostTargetPad:
     """TargetPad -> bicubic resize (short side = dim) -> centre crop -> RGB -> [0,1] CHW -> CLIP normalise
-    (data_utils.py:91-105)."""
-    from PIL import Image
-    pad = TargetPad(target_ratio, dim)
-    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
-    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+    (data_utils.py:91-105) with PIL on the host.  A class (not a closure) so that loader workers started from a fork server /
+    by spawn can unpickle it."""
 
-    def tf(image):
-        image = pad(image)
+    def __init__(self, target_ratio: float, dim: int):
+        self.pad, self.dim = TargetPad(target_ratio, dim), dim
+
+    def __call__(self, image):
+        from PIL import Image
+        dim = self.dim
+        image = self.pad(image)
         w, h = image.size
         if w <= h:
             nw, nh = dim, int(dim * h / w)
@@ -58,9 +60,12 @@ def targetpad_transform(target_ratio: float, dim: int) -> Callable:
         left, top = int(round((nw - dim) / 2.0)), int(round((nh - dim) / 2.0))
         image = image.crop((left, top, left + dim, top + dim)).convert("RGB")
         x = torch.from_numpy(np.asarray(image, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+        mean, std = torch.tensor(CLIP_MEAN).view(3, 1, 1), torch.tensor(CLIP_STD).view(3, 1, 1)
         return (x - mean) / std
 
-    return tf
+
+def targetpad_transform(target_ratio: float, dim: int) -> Callable:
+    return HostTargetPad(target_ratio, dim)
 
 
 class GpuTargetPad:

@@ -12,6 +12,7 @@ full sort and no nq x N host traffic.
 from __future__ import annotations
 
 from operator import itemgetter
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -84,7 +85,11 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     keep_raw=True (the reference's behaviour): raw = the stacked [N,257,D] fp32 tensor.
     keep_raw=<collection of names> (or False): raw = a `RawStore` holding the embeddings of those images only
     (`raw_dtype=torch.bfloat16` halves them; they are cast back to fp32 when a query is fused)."""
-    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=_pin(dataset), collate_fn=collate_fn)
+    # decode workers come from a fork SERVER (a small process started once): forking them from this process -- GPU context,
+    # gigabytes of mapped memory -- cost ~24 s per loader on the MI355X box (tools/c2_e2e.py); SPRC_LOADER_CONTEXT overrides
+    ctx = (os.environ.get("SPRC_LOADER_CONTEXT") or "forkserver") if num_workers > 0 else None
+    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=_pin(dataset), collate_fn=collate_fn,
+                        multiprocessing_context=ctx, persistent_workers=False)
     feats, raws, names = [], [], []
     split = getattr(dataset, "split", "")
     print(f"extracting {type(dataset).__name__} {split} index features")
@@ -122,12 +127,20 @@ def _stack_refs(name_to_feat: Dict[str, torch.Tensor], names: Sequence[str]) -> 
 
 
 # ---- CIRR validation ---------------------------------------------------------------------------------
+def _query_loader(dataset, batch_size: int, num_workers: int, **kw) -> DataLoader:
+    """Loader of a RELATIVE split: its items are names and captions, no pixels.  The reference forks 2-4 workers for it
+    (validate_blip.py:164,373; cirr_test_submission.py:149); forked from a process that holds a GPU context and a few GB of
+    pinned / mapped memory that start-up alone cost 26-36 s of a 50-s CIRR-val evaluation (tools/c2_e2e.py) for work that
+    takes 0.4 s in the main process.  `num_workers` is accepted for signature compatibility and ignored."""
+    del num_workers
+    return DataLoader(dataset=dataset, batch_size=batch_size, num_workers=0, pin_memory=False, **kw)
+
+
 def generate_cirr_val_predictions(blip_model, relative_val_dataset, index_names: List[str], index_features, txt_processors,
                                   batch_size: int = 32, num_workers: int = 2):
     """-> (sim[nq,N], reference_names, target_names, group_members, captions)   (validate_blip.py:359-410)"""
     print("Compute CIRR validation predictions")
-    loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True,
-                        collate_fn=collate_fn)
+    loader = _query_loader(relative_val_dataset, batch_size, num_workers, collate_fn=collate_fn)
     name_to_feat = dict(zip(index_names, index_features[1]))
     sims, target_names, group_members, reference_names, captions_all = [], [], [], [], []
     dev = blip_model.device
@@ -181,8 +194,7 @@ def generate_fiq_val_predictions(blip_model, relative_val_dataset, index_names: 
                                  save_memory: bool = False, batch_size: int = 16, num_workers: int = 4):
     """-> (sim[nq,N], target_names, reference_names, captions)   (validate_blip.py:149-207)"""
     print(f"Compute FashionIQ {getattr(relative_val_dataset, 'dress_types', '')} validation predictions")
-    loader = DataLoader(dataset=relative_val_dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True,
-                        collate_fn=collate_fn, shuffle=False)
+    loader = _query_loader(relative_val_dataset, batch_size, num_workers, collate_fn=collate_fn, shuffle=False)
     name_to_feat = dict(zip(index_names, index_features[-1]))
     sims, target_names, reference_names, captions_all = [], [], [], []
     dev = blip_model.device
@@ -220,7 +232,7 @@ def generate_cirr_test_predictions(blip_model, relative_test_dataset, index_name
                                    batch_size: int = 32, num_workers: int = 4):
     """-> (sim, reference_names, group_members, pairs_id, captions, name_to_feat)   (cirr_test_submission.py:135-190)"""
     print("Compute CIRR test predictions")
-    loader = DataLoader(dataset=relative_test_dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=True)
+    loader = _query_loader(relative_test_dataset, batch_size, num_workers)
     name_to_feat = dict(zip(index_names, index_features[1]))
     pairs_id, group_members, reference_names, sims, captions_all = [], [], [], [], []
     dev = blip_model.device
