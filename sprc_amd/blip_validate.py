@@ -88,9 +88,9 @@ def _rank0() -> bool:
 
 def _preprocess(gpu: bool, device):
     """(transform, DataLoader workers): the reference's targetpad_transform(1.25, 224) on the host (PIL) or with the pixel
-    work on the GPU (bit-identical; the transform then runs in the main process)."""
+    work on the GPU (bit-identical; loader workers then only decode, the transform runs in the main process)."""
     from .data_utils import targetpad_transform, targetpad_transform_gpu
-    return (targetpad_transform_gpu(1.25, 224, device), 0) if gpu else (targetpad_transform(1.25, 224), 2)
+    return (targetpad_transform_gpu(1.25, 224, device), 2) if gpu else (targetpad_transform(1.25, 224), 2)
 
 
 def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16", index_cache=None, gpu_preprocess=False,

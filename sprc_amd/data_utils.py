@@ -109,6 +109,14 @@ class GpuTargetPad:
         return out
 
 
+class DecodeRGB:
+    """The host half of `GpuTargetPad`: PIL image -> uint8 RGB tensor [H, W, 3] (_convert_image_to_rgb, data_utils.py:74-75).
+    What loader WORKERS run when the pixel work is on the GPU (sprc_amd/harness.py: extract_index_blip_features)."""
+
+    def __call__(self, image) -> torch.Tensor:
+        return torch.from_numpy(np.array(image.convert("RGB"), dtype=np.uint8, order="C"))
+
+
 def targetpad_transform_gpu(target_ratio: float, dim: int, device="cuda") -> Callable:
     return GpuTargetPad(target_ratio, dim, device)
 

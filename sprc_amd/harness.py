@@ -35,6 +35,25 @@ def collate_fn(batch: list):
     return torch.utils.data.dataloader.default_collate(batch)
 
 
+def _collate_ragged(batch: list):
+    """(names, [uint8 HWC tensors of different sizes]) with `None` items dropped."""
+    batch = [b for b in batch if b is not None]
+    return [b[0] for b in batch], [b[1] for b in batch]
+
+
+def _decode_only(dataset):
+    """-> (the dataset's on-device transform, a shallow copy of the dataset that only decodes); Subset-aware."""
+    import copy
+    from torch.utils.data import Subset
+    from .data_utils import DecodeRGB
+    if isinstance(dataset, Subset):
+        tf, inner = _decode_only(dataset.dataset)
+        return tf, Subset(inner, dataset.indices)
+    clone = copy.copy(dataset)
+    tf, clone.preprocess = dataset.preprocess, DecodeRGB()
+    return tf, clone
+
+
 def _pin(dataset) -> bool:
     """pin_memory for the loader unless the dataset's transform already returns device tensors (data_utils.GpuTargetPad)."""
     while hasattr(dataset, "dataset"):              # torch.utils.data.Subset
@@ -85,11 +104,18 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     keep_raw=True (the reference's behaviour): raw = the stacked [N,257,D] fp32 tensor.
     keep_raw=<collection of names> (or False): raw = a `RawStore` holding the embeddings of those images only
     (`raw_dtype=torch.bfloat16` halves them; they are cast back to fp32 when a query is fused)."""
+    # pixel work on the GPU (data_utils.GpuTargetPad) and workers asked for: the workers only DECODE (a copy of the dataset whose
+    # transform is DecodeRGB), the transform runs here on what they hand over -- PNG / JPEG decoding is the slow part of a gallery
+    # pass (2297 files: 5.2 s on one core against 1.6 s of GPU work)
+    gpu_tf = None
+    if num_workers > 0 and not _pin(dataset):
+        gpu_tf, dataset = _decode_only(dataset)
     # decode workers come from a fork SERVER (a small process started once): forking them from this process -- GPU context,
     # gigabytes of mapped memory -- cost ~24 s per loader on the MI355X box (tools/c2_e2e.py); SPRC_LOADER_CONTEXT overrides
     ctx = (os.environ.get("SPRC_LOADER_CONTEXT") or "forkserver") if num_workers > 0 else None
-    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=_pin(dataset), collate_fn=collate_fn,
-                        multiprocessing_context=ctx, persistent_workers=False)
+    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=gpu_tf is None and _pin(dataset),
+                        collate_fn=_collate_ragged if gpu_tf is not None else collate_fn, multiprocessing_context=ctx,
+                        persistent_workers=False)
     feats, raws, names = [], [], []
     split = getattr(dataset, "split", "")
     print(f"extracting {type(dataset).__name__} {split} index features")
@@ -98,6 +124,8 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     wanted = set() if keep_raw in (False, None) else (set(keep_raw) if subset else None)
     rows: Dict[int, torch.Tensor] = {}
     for batch_names, images in tqdm(loader):
+        if gpu_tf is not None:
+            images = torch.stack([gpu_tf(im) for im in images])
         images = images.to(dev, non_blocking=True)
         f, r = blip_model.extract_target_features(images, mode="mean")
         if raw_dtype is not None:
