@@ -156,3 +156,34 @@ def test_feature_store_round_trip(tmp_path):
         save_index(tmp_path / "short.safetensors", feats, names[:-1])
     with pytest.raises(ValueError, match=r"\[N,32,E\]"):
         save_index(tmp_path / "shape.safetensors", feats[:, :8], names)
+
+
+def test_query_loaders_stay_in_the_main_process_and_gallery_workers_only_decode():
+    """Loader policy of the evaluation harness (tools/c2_e2e.py measured 24-36 s per forked loader): relative splits load
+    in-process whatever `num_workers` says; with an on-device transform the workers get a decode-only copy of the dataset."""
+    import pickle
+    from torch.utils.data import Subset
+    from sprc_amd import harness as H
+    from sprc_amd.data_utils import DecodeRGB, HostTargetPad, targetpad_transform
+
+    rel = [("a", "b", "cap", ["a", "b"])] * 5
+    loader = H._query_loader(rel, 2, 4, collate_fn=H.collate_fn)
+    assert loader.num_workers == 0 and not loader.pin_memory and len(list(loader)) == 3
+
+    class OnDevice:
+        on_device = True
+
+    class DS:
+        def __init__(self):
+            self.preprocess, self.names = OnDevice(), ["x", "y", "z"]
+
+    ds = DS()
+    tf, clone = H._decode_only(Subset(ds, [0, 2]))
+    assert tf is ds.preprocess and isinstance(clone, Subset) and list(clone.indices) == [0, 2]
+    assert isinstance(clone.dataset.preprocess, DecodeRGB) and isinstance(ds.preprocess, OnDevice)      # the original is untouched
+    assert not H._pin(ds) and H._pin(clone)
+    # what fork-server workers have to unpickle
+    assert isinstance(pickle.loads(pickle.dumps(targetpad_transform(1.25, 224))), HostTargetPad)
+    assert isinstance(pickle.loads(pickle.dumps(DecodeRGB())), DecodeRGB)
+    names, imgs = H._collate_ragged([("n0", torch.zeros(3, 4, 3, dtype=torch.uint8)), None, ("n1", torch.zeros(5, 2, 3, dtype=torch.uint8))])
+    assert names == ["n0", "n1"] and [tuple(i.shape) for i in imgs] == [(3, 4, 3), (5, 2, 3)]
