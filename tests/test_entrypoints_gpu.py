@@ -153,3 +153,51 @@ def test_cirr_test_submission_on_disk(world):
     want_rr, _ = O.cirr_test_dicts(sim, ref, grp, [x["pairid"] for x in world["trip"]], world["names"], rerank_scores=prob)
     for k, v in want_rr.items():
         assert rec2[k] == v
+
+
+def test_blip_validate_fashioniq_on_disk(world):
+    """`--dataset fashionIQ` on a FashionIQ-layout directory (captions / image_splits / images per dress type): the printed
+    Recall@10/50 equal an independent evaluation (PIL-exact transform + CPU oracle + the oracle's metric code); the PIL
+    transform in fork-server workers, the GPU transform with decode-only workers and the feature store agree."""
+    from sprc_amd import blip_validate as bv
+    from sprc_amd.processors import BlipCaptionProcessor, fiq_compose_caption
+    from sprc_amd.tokenizer import BertWordPieceTokenizer
+    root, cfg, sd = world["root"], world["cfg"], world["sd"]
+    fiq = root / "fashionIQ_dataset"
+    for sub in ("captions", "image_splits", "images"):
+        (fiq / sub).mkdir(parents=True, exist_ok=True)
+    rng = np.random.default_rng(11)
+    want = {}
+    for d, n_img, nq in (("dress", 9, 6), ("shirt", 7, 5)):
+        names, arrays = [], {}
+        for i in range(n_img):
+            arr = synth_image(200 + 37 * i, 260 - 11 * i, 300 + i + len(d))
+            name = f"{d[0]}{i:04d}"
+            Image.fromarray(arr).save(fiq / "images" / f"{name}.png")
+            names.append(name)
+            arrays[name] = arr
+        trip = []
+        for q in range(nq):
+            ref = int(rng.integers(0, n_img))
+            tgt = int((ref + 1 + rng.integers(0, n_img - 1)) % n_img)
+            caps = [" ".join(rng.choice(WORDS[:20], size=int(rng.integers(2, 6))).tolist()) for _ in range(2)]
+            trip.append({"candidate": names[ref], "target": names[tgt], "captions": caps})
+        (fiq / "captions" / f"cap.{d}.val.json").write_text(json.dumps(trip))
+        (fiq / "image_splits" / f"split.{d}.val.json").write_text(json.dumps(names))
+        # independent evaluation
+        images = torch.from_numpy(np.stack([P.targetpad_transform(arrays[n]) for n in names]))
+        proc, tok = BlipCaptionProcessor(), BertWordPieceTokenizer()
+        caps = [proc(fiq_compose_caption(t["captions"][0], t["captions"][1])) for t in trip]
+        t = tok(caps, padding="max_length", truncation=True, max_length=32, return_tensors="pt")
+        n2i = {n: i for i, n in enumerate(names)}
+        ref_idx = torch.tensor([n2i[x["candidate"]] for x in trip])
+        tgt_idx = np.array([n2i[x["target"]] for x in trip])
+        with torch.no_grad():
+            feats, raw = O.extract_target_features(sd, cfg, images)
+            sim = O.inference(sd, cfg, raw[ref_idx], feats, t.input_ids, t.attention_mask).numpy()
+        want[d] = O.fiq_metrics(sim, tgt_idx)
+    out = bv.blip_validate_fiq(["dress", "shirt"], "blip2_cir_align_prompt", "pretrain", str(root / "ckpt.pt"), "fp32", None, False, DEPTH)
+    for d in ("dress", "shirt"):
+        assert (out[f"{d}_recall_at10"], out[f"{d}_recall_at50"]) == pytest.approx(want[d], abs=1e-4)
+    assert out["average_recall"] == pytest.approx((np.mean([want[d][0] for d in want]) + np.mean([want[d][1] for d in want])) / 2, abs=1e-4)
+    assert bv.blip_validate_fiq(["dress", "shirt"], "blip2_cir_align_prompt", "pretrain", str(root / "ckpt.pt"), "fp32", None, True, DEPTH) == out
