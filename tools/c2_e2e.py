@@ -59,8 +59,9 @@ def build(root: Path):
         members = [names[i] for i in rng.permutation([ref, tgt, *others])]
         cap = " ".join(rng.choice(WORDS[:20], size=int(rng.integers(2, 9))).tolist()).capitalize() + "."
         trip.append({"pairid": 100 + q, "reference": names[ref], "target_hard": names[tgt], "caption": cap, "img_set": {"members": members}})
-    (cirr / "captions" / "cap.rc2.val.json").write_text(json.dumps(trip))
-    (cirr / "image_splits" / "split.rc2.val.json").write_text(json.dumps(split))
+    for sp in ("val", "test1"):                             # the same files serve as the test1 split (config C4's sizes are alike)
+        (cirr / "captions" / f"cap.rc2.{sp}.json").write_text(json.dumps(trip))
+        (cirr / "image_splits" / f"split.rc2.{sp}.json").write_text(json.dumps(split))
     vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + WORDS + [".", ","]
     vocab += [f"tok{i}" for i in range(30522 - len(vocab))]
     (root / "vocab.txt").write_text("\n".join(vocab) + "\n")
@@ -87,6 +88,15 @@ def main():
         torch.cuda.synchronize()
         out[tag] = time.perf_counter() - t
         print(f"[c2_e2e] {tag}: {out[tag]:.1f} s   R@1 {m['recall_at1']:.2f} R@10 {m['recall_at10']:.2f} Rs@1 {m['group_recall_at1']:.2f}", flush=True)
+    # the test-submission entry point (cirr_test_submission.py:203-222), without and with the stage-2 rerank of the top-50
+    from sprc_amd import cirr_test_submission as cts
+    for tag, extra in (("test submission", []), ("test submission + rerank", ["--rerank", "true"])):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        cts.main(["--model-path", str(root / "ckpt.pt"), "--gpu-preprocess", *extra])
+        torch.cuda.synchronize()
+        out[tag] = time.perf_counter() - t
+        print(f"[c2_e2e] {tag}: {out[tag]:.1f} s", flush=True)
     print(json.dumps({"n_images": N_IMG, "n_queries": NQ, "seconds": out}))
 
 
