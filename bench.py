@@ -36,7 +36,8 @@ MFMA_FP8_PEAK_TFLOPS = 5000.0                                     # dense fp8 (M
 HBM_PEAK_GBS = 8000.0
 # the GEMM class = every launch of these kernels (sprc_amd/csrc/gemm.hip); the 256x256 anti-phase kernel carries > 95 % of
 # the class time at the bench shapes, the 128x128 kernel the remainder rows and the small Q-Former products
-GEMM_KERNELS = {"bf16": "sprc::gemm_anti_kernel<...> (256x256 anti-phase, dominant) + sprc::gemm_kernel<bf16,...> (128x128)",
+GEMM_KERNELS = {"fp16": "sprc::gemm_anti_kernel<f16,...> (256x256 anti-phase, v_mfma_f32_32x32x16_f16, dominant) + sprc::gemm_kernel<f16,...> (128x128 / 64x64)",
+                "bf16": "sprc::gemm_anti_kernel<...> (256x256 anti-phase, dominant) + sprc::gemm_kernel<bf16,...> (128x128)",
                 "fp8": "sprc::gemm_anti_kernel<..., FP8> (256x256 anti-phase, MX-scaled e4m3 MFMA: ViT qkv / fc1 / fc2) + the bf16 kernels (proj, Q-Former)",
                 "fp32": "sprc::gemm_kernel<float,...> (exact fp32 MFMA)"}
 
@@ -57,7 +58,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8"], help="fp8: bf16 engine whose ViT qkv / fc1 / fc2 GEMMs run on e4m3fn operands (BASELINE config C5)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp8"], help="fp16: fp16 MFMA operands (the reference's GPU autocast precision; the bf16 rate); fp8: bf16 engine whose ViT qkv / fc1 / fc2 GEMMs run on e4m3fn operands (BASELINE config C5)")
     ap.add_argument("--backbone", default="pretrain", choices=["pretrain", "pretrain_vitL"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=10, help="record per-launch HIP events on every Nth timed step, starting with the first (0 = never)")

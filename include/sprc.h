@@ -15,8 +15,8 @@
  *   - return 0 on success, a negative SPRC_E* code otherwise; sprc_last_error() returns a
  *     thread-local message; no C++ exception crosses the boundary;
  *   - all matrices are row-major; "ld*" are leading dimensions in ELEMENTS;
- *   - compute dtype: SPRC_BF16 (bf16 MFMA operands, fp32 accumulate, fp32 residual stream /
- *     LayerNorm / softmax) or SPRC_F32 (exact fp32 MFMA, parity mode).
+ *   - compute dtype: SPRC_BF16 or SPRC_F16 (16-bit MFMA operands, fp32 accumulate, fp32 residual
+ *     stream / LayerNorm / softmax) or SPRC_F32 (exact fp32 MFMA, parity mode).
  */
 #ifndef SPRC_H
 #define SPRC_H
@@ -28,12 +28,15 @@
 extern "C" {
 #endif
 
-#define SPRC_ABI_VERSION 2
+#define SPRC_ABI_VERSION 3
 
 enum { SPRC_OK = 0, SPRC_EINVAL = -1, SPRC_ELAUNCH = -2, SPRC_EWORKSPACE = -3, SPRC_EUNSUPPORTED = -4 };
 enum { SPRC_F32 = 0, SPRC_BF16 = 1,
-       SPRC_F16 = 2 /* OUTPUT-only dtype of sprc_gemm: a residual-branch output ("delta") that sprc_layernorm adds to the
-                       fp32 residual stream (11-bit mantissa: 8x finer than the bf16 GEMM operands) */,
+       SPRC_F16 = 2 /* IEEE half.  As a COMPUTE dtype (ABI 3): fp16 MFMA operands (v_mfma_f32_32x32x16_f16, the bf16 rate), fp32
+                       accumulate / residual stream / LayerNorm / softmax -- the reference's own GPU precision (fp16 autocast,
+                       lavis/models/blip2_models/blip2.py:36-44, eva_vit.py:410-425), 8x finer operand rounding than bf16.
+                       Also an OUTPUT dtype of a bf16 sprc_gemm: a residual-branch output ("delta") that sprc_layernorm
+                       adds to the fp32 residual stream */,
        SPRC_FP8 = 3 /* OCP e4m3fn (the gfx950 fp8; NOT MI300's fnuz): GEMM operands with a per-tensor activation scale and
                        per-output-channel weight scales, fp32 accumulation (BASELINE.json config C5: "ViT-L, fp8 MFMA") */ };
 enum { SPRC_ACT_NONE = 0, SPRC_ACT_GELU = 1, SPRC_ACT_QUICKGELU = 2 };
@@ -71,12 +74,15 @@ int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s);
 
 /* fp32 -> bf16 (round-to-nearest-even) weight/feature packing. */
 int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s);
+/* fp32 -> `dtype` (SPRC_BF16 or SPRC_F16), round-to-nearest-even. */
+int sprc_cast_f32_to_16(const float* src, void* dst, size_t n, int32_t dtype, sprc_stream s);
 
 /* C = epilogue(A[M,K] . W[N,K]^T + bias) -- replaces every nn.Linear / F.linear on the path:
  * eva_vit.py:123,146,55-60; clip_vit.py:132-139; Qformer.py:135-137,201-211,291-293,365,377;
  * align_prompt.py:348,385.  A and W are `dtype`; bias/resid fp32; out is `out_dtype`.
- * K % 64 == 0 (bf16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (bf16) / 4 (f32) elements.
- * out_dtype SPRC_F16: bf16 operands only, no activation / residual / max32 (see sprc_layernorm_args.add16).
+ * K % 64 == 0 (bf16, fp16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (16-bit) / 4 (f32) elements.
+ * dtype SPRC_F16: outputs fp16 or f32, every epilogue.
+ * out_dtype SPRC_F16 with bf16 operands: no activation / residual / max32 (see sprc_layernorm_args.add16).
  * dtype SPRC_FP8: K % 128 == 0; outputs bf16 / f32 (plain epilogue, residual allowed) or fp8 (any activation).
  *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
  * max32 != 0: "similarity" epilogue -- rows of A are query vectors, rows of W are gallery tokens (32 per

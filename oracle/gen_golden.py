@@ -14,6 +14,8 @@ Files written:
   tests/golden/full_clip.npz   full depth ViT-L (23 blocks), 2 images, 3 queries   (--full)
   tests/golden/planted_eva.npz planted-structure weights (scores spread > 1.0), depth-4 ViT-g, 160 gallery x 72 queries:
                                scores, planned targets, the reference's own metrics / submission dicts on them
+  tests/golden/planted_full_eva.npz  the same at FULL depth (39 blocks), 96 gallery x 48 queries (--full): the case the
+                               16-bit engines are held to max|dsim| < 1e-3 on
   tests/golden/train_eva.npz   training forward: the reference's three losses (loss_itc, loss_rtc, loss_align) on 5 triplets
   tests/golden/rerank_eva.npz  stage-2 rerank: the reference's Blip2QformerCirRerank.inference_rerank on 3 queries x 4 candidates
   tests/golden/metrics.json    reference compute_cirr_val_metrics / compute_fiq_val_metrics /
@@ -274,7 +276,7 @@ def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int =
     s_sorted = np.sort(sim, axis=1)
     gaps = np.diff(s_sorted, axis=1)
     np.savez_compressed(
-        out, model_type="pretrain", vit_depth=vit_depth, seed=seed, n_img=n_img, n_q=n_q,
+        out, model_type="pretrain", vit_depth=cfg.vit.depth, seed=seed, n_img=n_img, n_q=n_q,
         image_probe=_np(images[:4, :, 0, :4]), input_ids=ids.numpy(), attention_mask=mask.numpy(), ref_index=refn,
         tgt_index=tgt, groups=groups, sim=sim, fusion=fusion, feats_head=_np(feats[:4]), raw_head=_np(raw[:2][:, ROWS]),
         cirr=np.array(cirr, dtype=np.float64), fiq=np.array(fiq, dtype=np.float64),
@@ -385,6 +387,8 @@ def main():
         rerank_goldens(GOLD / "rerank_eva.npz")
     if want("planted"):
         planted_goldens(GOLD / "planted_eva.npz")
+    if a.full and want("planted_full"):      # full depth (39 blocks), 96 gallery images x 48 queries: the dtype-parity case
+        planted_goldens(GOLD / "planted_full_eva.npz", n_img=96, n_q=48, vit_depth=None)
     if a.full and want("full_eva"):
         model_goldens("pretrain", None, n_img=2, n_q=3, out=GOLD / "full_eva.npz")
     if a.full and want("full_clip"):

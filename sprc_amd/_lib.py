@@ -12,10 +12,16 @@ from pathlib import Path
 # SPRC_LIB_PATH: an A/B build of the same library (tools/build_variant.sh); never a different implementation
 LIB_PATH = Path(os.environ.get("SPRC_LIB_PATH") or (Path(__file__).resolve().parent / "libsprc_hip.so"))
 
-SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: GEMM output only (residual deltas); FP8: OCP e4m3fn operands
-ABI_VERSION = 2
+SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: IEEE half (compute dtype since ABI 3); FP8: OCP e4m3fn operands
+ABI_VERSION = 3
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
-DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16, "fp8": SPRC_BF16}     # "fp8" engine: bf16 model + fp8 ViT GEMMs
+DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16, "fp16": SPRC_F16, "f16": SPRC_F16,
+          "fp8": SPRC_BF16}     # "fp8" engine: bf16 model + fp8 ViT GEMMs
+
+
+def is16(dt: int) -> bool:
+    """16-bit MFMA operand engines (bf16, or fp16 = the reference's GPU autocast precision)."""
+    return dt in (SPRC_BF16, SPRC_F16)
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 
@@ -99,6 +105,7 @@ SIGNATURES = {
     "sprc_prof_enable": (i32, [i32]),
     "sprc_prof_collect": (i32, [C.POINTER(ProfEntry)]),
     "sprc_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
+    "sprc_cast_f32_to_16": (i32, [vp, vp, sz, i32, vp]),
     "sprc_absmax_bf16": (i32, [vp, sz, vp, vp]),
     "sprc_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "sprc_gemm_pair": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),

@@ -153,7 +153,7 @@ def main(argv=None):
     p.add_argument("--blip-model-name", default="blip2_cir_align_prompt", type=str)
     p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
     p.add_argument("--model-path", type=str)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--index-cache", default=None, help="directory of gallery feature stores (sprc_amd/index.py): encode once, reuse")
     p.add_argument("--gpu-preprocess", action="store_true", help="pad / bicubic resize / crop / normalise on the GPU (bit-identical to the PIL transform)")
     p.add_argument("--vit-depth", type=int, default=None, help="truncate the ViT to N blocks (entry-point smoke tests only)")

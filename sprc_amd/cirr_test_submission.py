@@ -44,7 +44,7 @@ def main(argv=None):
     p.add_argument("--model-path", type=str)
     p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
     p.add_argument("--rerank", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--gpu-preprocess", action="store_true", help="image transform on the GPU (bit-identical to the PIL transform)")
     p.add_argument("--vit-depth", type=int, default=None, help="truncate the ViT to N blocks (entry-point smoke tests only)")
     a = p.parse_args(argv)

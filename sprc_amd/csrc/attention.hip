@@ -24,8 +24,21 @@ constexpr float LOG2E = 1.4426950408889634f;
 // sum of the two bf16 values packed in a dword, as floats.  The softmax denominator is accumulated from the ROUNDED
 // probabilities that enter the P.V MFMAs: numerator and denominator then carry the same rounding, and the error of the
 // weighted average scales with |v - mean(v)| instead of |v| (first order: sum_k p_k eps_k (v_k - vbar) / sum_k p_k).
+template <bool F16>
 __device__ __forceinline__ float rounded_pair_sum(uint32_t pk) {
-    return __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
+    if constexpr (F16) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+        const f16x2_t v = __builtin_bit_cast(f16x2_t, pk);
+        return (float)v[0] + (float)v[1];
+    } else {
+        return __uint_as_float(pk << 16) + __uint_as_float(pk & 0xffff0000u);
+    }
+}
+// one MFMA k-step on 16-bit fragments of the engine's operand type (F16: IEEE half, else bf16): same layout, same rate
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const u32x4& a, const u32x4& b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 struct AttnParams {
@@ -56,7 +69,7 @@ __device__ __forceinline__ const char* kv_token(const AttnParams& p, const char*
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int DHP, int NW>
+template <int DHP, int NW, bool F16>
 __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = DHP / 16;              // MFMA k-steps of QK^T
@@ -78,17 +91,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
     // Q^T fragment (B operand) of query tile qt: lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8].  The wave's FIRST tile is
     // fetched here, before the K / V staging, so its memory round trip runs under the staging instead of after the barrier
     // (the Q-Former launches are a few tiles per workgroup: that round trip was a fifth of their time).
-    auto load_q = [&](int qt, bf16x8 (&qf)[KS]) {
+    auto load_q = [&](int qt, u32x4 (&qf)[KS]) {
         const int qrow = min(qt * 32 + r32, p.Tq - 1);
         const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d0 = ks * 16 + half * 8;
             const u32x4 v = *reinterpret_cast<const u32x4*>(qptr + (d0 < dh ? d0 : 0) * 2);
-            qf[ks] = __builtin_bit_cast(bf16x8, d0 < dh ? v : u32x4{0u, 0u, 0u, 0u});
+            qf[ks] = d0 < dh ? v : u32x4{0u, 0u, 0u, 0u};
         }
     };
-    bf16x8 qf[KS];
+    u32x4 qf[KS];
     load_q(min(wave, nqt - 1), qf);
 
     // ---- stage K (row-major, zero padded) and V transposed (VT[d][key], two keys per 32-bit write).  Global loads are
@@ -165,8 +178,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
             const char* krow = sK + (kt * 32 + r32) * KROW + half * 16;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 32);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                const u32x4 kf = *reinterpret_cast<const u32x4*>(krow + ks * 32);
+                s = mfma16<F16>(kf, qf[ks], s);
             }
             float m_new, psum = 0.f;
             if (p.key_mask == nullptr && (plain_tail || kt + 1 < nkt)) {
@@ -210,17 +223,15 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
             // P^T fragments (B operand): k-slot j uses this lane's regs 8j..8j+7
-            bf16x8 pf[2];
+            u32x4 pf[2];
             psum = 0.f;                          // re-summed from the rounded probabilities (see rounded_pair_sum)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                u32x4 pk;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);   // v_cvt_pk_bf16_f32
-                    psum += rounded_pair_sum(pk[e]);
+                    pf[j][e] = pack16x2<F16>(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);   // v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32
+                    psum += rounded_pair_sum<F16>(pf[j][e]);
                 }
-                pf[j] = __builtin_bit_cast(bf16x8, pk);
             }
             l_run = l_run * alpha + psum;
             // O^T += V^T . P^T ; A operand lane (d = r32, half): keys {16j+4half+0..3, 16j+8+4half+0..3}
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
                     const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (16 * j) * 2);
                     const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (16 * j + 8) * 2);
                     const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[j], o[dt], 0, 0, 0);
+                    o[dt] = mfma16<F16>(vv, pf[j], o[dt]);
                 }
             }
         }
@@ -248,8 +259,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
                     const int d0 = dt * 32 + 8 * g + 4 * half;
                     if (d0 < dh) {
                         uint2 pk;
-                        pk.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
-                        pk.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+                        pk.x = pack16x2<F16>(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+                        pk.y = pack16x2<F16>(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
                         *reinterpret_cast<uint2*>(optr + d0 * 2) = pk;
                     }
                 }
@@ -289,7 +300,7 @@ __device__ __forceinline__ u32x4 attn_load16(__amdgpu_buffer_rsrc_t rs, uint32_t
 }
 constexpr uint32_t ATTN_OOB = 0x80000000u;   // beyond every descriptor's range (an image's K/V rows span < 2 GiB)
 
-template <int DHP, bool ONES, int NW, bool ABLATE = false>
+template <int DHP, bool ONES, int NW, bool F16, bool ABLATE = false>
 __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, int nqb, int xcd_map, int debug_arg) {
     // the production instantiation folds every ablation branch away: a run-time branch around the loads or the tile math makes
     // the compiler merge its wait counters at the join and drain the whole load queue there
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
         for (int u = 0; u < KPT; ++u)
             if (k_row[u] < 32) *reinterpret_cast<u32x4*>(sK + k_lds[u]) = g.kreg[u];
         if (v_item) {
-            if (v_ones) va[0] = vb[0] = 0x3f80u;                 // bf16 1.0 in row dh for both keys of the pair
+            if (v_ones) va[0] = vb[0] = F16 ? 0x3c00u : 0x3f80u;  // 1.0 (fp16 / bf16) in row dh for both keys of the pair
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {                     // rows (e, e+1) of the chunk: low / high halves of dword e/2
                 const uint32_t a = va[e >> 1], c = vb[e >> 1];
@@ -388,13 +399,13 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
     const int qt = qb * NW + wave;
     const int qrow = min(qt * 32 + r32, p.Tq - 1);
     const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
-    bf16x8 qf[KS];
+    u32x4 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const int d0 = ks * 16 + half * 8;
         u32x4 val = {0u, 0u, 0u, 0u};
         if (d0 < dh && !(debug & 32)) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
-        qf[ks] = __builtin_bit_cast(bf16x8, val);
+        qf[ks] = val;
     }
     f32x16 o[DT];
 #pragma unroll
@@ -417,8 +428,8 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
         for (int ks = 0; ks < KS; ++ks) {
             // (issuing all KS fragment reads ahead of the first MFMA through inline asm changed nothing: 124-127 us either way --
             // with three waves per SIMD the other waves cover the read latency)
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + ks * 32);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(krow + ks * 32);
+            s = mfma16<F16>(kf, qf[ks], s);
         }
         if constexpr (TAIL) {                   // padded keys: key of reg r = kt*32 + (r&3) + 8*(r>>2) + 4*half
 #pragma unroll
@@ -441,17 +452,15 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run));
-        bf16x8 pf[2];
+        u32x4 pf[2];
         float psum = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            u32x4 pk;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pk[e] = pack_bf16x2(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
-                if constexpr (!ONES) psum += rounded_pair_sum(pk[e]);       // the denominator sums what the MFMA multiplies
+                pf[j][e] = pack16x2<F16>(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
+                if constexpr (!ONES) psum += rounded_pair_sum<F16>(pf[j][e]);       // the denominator sums what the MFMA multiplies
             }
-            pf[j] = __builtin_bit_cast(bf16x8, pk);
         }
         if constexpr (!ONES) l_run += psum;
         u32x4 vf[DT][2];                        // V^T fragments: issued together, ahead of the softmax arithmetic's tail
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[dt][j]), pf[j], o[dt], 0, 0, 0);
+                o[dt] = mfma16<F16>(vf[dt][j], pf[j], o[dt]);
     };
 
     commit(stg[0], 0);
@@ -514,8 +523,8 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
             const int d0 = dt * 32 + 8 * g + 4 * half;
             if (d0 < dh) {
                 uint2 pk;
-                pk.x = pack_bf16x2(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
-                pk.y = pack_bf16x2(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+                pk.x = pack16x2<F16>(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+                pk.y = pack16x2<F16>(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
                 *reinterpret_cast<uint2*>(so + r32 * ORS + d0 * 2) = pk;
             }
         }
@@ -591,7 +600,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
     }
 }
 
-template <int DHP, int NW>
+template <int DHP, int NW, bool F16>
 static int launch_bf16(const AttnParams& p, hipStream_t st) {
     const int Tkp = (p.Tk + 31) & ~31;
     const size_t lds = (size_t)Tkp * (DHP * 2 + 16) + (size_t)DHP * (Tkp * 2 + 8) + (size_t)Tkp * 4;
@@ -599,7 +608,7 @@ static int launch_bf16(const AttnParams& p, hipStream_t st) {
         set_error("sprc_attention: Tk=%d needs %zu bytes of LDS (max 163840)", p.Tk, lds);
         return SPRC_EUNSUPPORTED;
     }
-    auto kern = attn_bf16_kernel<DHP, NW>;
+    auto kern = attn_bf16_kernel<DHP, NW, F16>;
     static size_t attr[64] = {0};               // hipFuncSetAttribute applies to the current device: one high-water mark per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -613,7 +622,7 @@ static int launch_bf16(const AttnParams& p, hipStream_t st) {
     return SPRC_OK;
 }
 
-template <int DHP, bool ONES, int NW>
+template <int DHP, bool ONES, int NW, bool F16>
 static int launch_stream(const AttnParams& p, hipStream_t st) {
     constexpr int BUF = 32 * (DHP * 2 + 16) + DHP * 72;
     constexpr int LDS = 2 * BUF > NW * 32 * (DHP * 2 + 16) ? 2 * BUF : NW * 32 * (DHP * 2 + 16);
@@ -623,12 +632,51 @@ static int launch_stream(const AttnParams& p, hipStream_t st) {
     static const int debug = [] { const char* e = getenv("SPRC_ATTN_DEBUG"); return e ? atoi(e) : 0; }();
     static const int xcd = [] { const char* e = getenv("SPRC_ATTN_XCD"); return e ? atoi(e) : 1; }();
     const int xmap = !xcd ? 0 : (xcd == 3 && (bh % 8) == 0) ? 1 : (p.B % 8) == 0 ? 2 : (bh % 8) == 0 ? 1 : 0;
-    if (debug != 0) hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES, NW, true>), dim3(bh * nqb), dim3(64 * NW), LDS, st, p, nqb, xmap, debug);
-    else hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES, NW, false>), dim3(bh * nqb), dim3(64 * NW), LDS, st, p, nqb, xmap, 0);
+    if constexpr (!F16) {
+        if (debug != 0) {
+            hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES, NW, false, true>), dim3(bh * nqb), dim3(64 * NW), LDS, st, p, nqb, xmap, debug);
+            SPRC_CHECK_LAUNCH("sprc_attention(bf16, streaming, ablation)");
+            return SPRC_OK;
+        }
+    }
+    hipLaunchKernelGGL((attn_stream_kernel<DHP, ONES, NW, F16, false>), dim3(bh * nqb), dim3(64 * NW), LDS, st, p, nqb, xmap, 0);
     SPRC_CHECK_LAUNCH("sprc_attention(bf16, streaming)");
     return SPRC_OK;
 }
 
+}  // namespace sprc
+
+namespace sprc {
+// 16-bit engines (F16: fp16 operands, else bf16): kernel choice by shape
+template <bool F16>
+static int attention16(const sprc_attention_args* a, const AttnParams& p, bool two, hipStream_t st) {
+    SPRC_REQUIRE(a->head_dim % 8 == 0 && a->head_dim <= 96, "sprc_attention(16-bit): head_dim=%d unsupported", a->head_dim);
+    SPRC_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0,
+                 "sprc_attention(16-bit): leading dims must be multiples of 8");
+    SPRC_REQUIRE(((uintptr_t)a->q % 16) == 0 && ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0 &&
+                     ((uintptr_t)a->out % 8) == 0, "sprc_attention(16-bit): misaligned pointer");
+    SPRC_REQUIRE(!two || (a->ldk2 % 8 == 0 && a->ldv2 % 8 == 0 && ((uintptr_t)a->k2 % 16) == 0 && ((uintptr_t)a->v2 % 16) == 0),
+                 "sprc_attention(16-bit): second key segment misaligned");
+    const bool small = a->Tq <= 128;
+    // long query axes without a key mask (the ViT blocks): streaming kernel, four workgroups of three waves per CU (153 VGPRs;
+    // 5- and 9-wave workgroups measured 268 / 170 us against 125: fewer co-resident workgroups).
+    // (SPRC_ATTN_STREAM=0 keeps the resident-K/V kernel for A/B runs)
+    static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
+    if (stream && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
+        if (a->head_dim <= 64) return launch_stream<64, false, 3, F16>(p, st);
+        if (a->head_dim == 88) return launch_stream<96, true, 3, F16>(p, st);     // denominator from the ones row of the padded V^T tile
+        return launch_stream<96, false, 3, F16>(p, st);
+    }
+    // 257 tokens = 9 query tiles: nine waves (one tile each, the K / V staging shared by nine) beat eight waves of which
+    // one carries two tiles: 209 -> 195 us per ViT-g layer
+    const int nqt = (a->Tq + 31) / 32;
+    if (nqt == 9) {
+        if (a->head_dim <= 64) return launch_bf16<64, 9, F16>(p, st);
+        return launch_bf16<96, 9, F16>(p, st);
+    }
+    if (a->head_dim <= 64) return small ? launch_bf16<64, 4, F16>(p, st) : launch_bf16<64, 8, F16>(p, st);
+    return small ? launch_bf16<96, 4, F16>(p, st) : launch_bf16<96, 8, F16>(p, st);
+}
 }  // namespace sprc
 
 extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
@@ -643,39 +691,11 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
                  (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale,
                  a->Tk, (const char*)a->k2, a->ldk2, (const char*)a->v2, a->ldv2, a->kv_index, a->kv2_index};
     hipStream_t st = (hipStream_t)s;
-    const double bh = (double)a->B * a->H, esz = a->dtype == SPRC_BF16 ? 2.0 : 4.0;
+    const double bh = (double)a->B * a->H, esz = (double)dtype_size(a->dtype);
     ProfScope prof(SPRC_K_ATTN, st, 4.0 * bh * a->Tq * (double)Tk_all * a->head_dim,
                    bh * a->head_dim * esz * (2.0 * a->Tq + 2.0 * Tk_all));
-    if (a->dtype == SPRC_BF16) {
-        SPRC_REQUIRE(a->head_dim % 8 == 0 && a->head_dim <= 96, "sprc_attention(bf16): head_dim=%d unsupported", a->head_dim);
-        SPRC_REQUIRE(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 4 == 0,
-                     "sprc_attention(bf16): leading dims must be multiples of 8");
-        SPRC_REQUIRE(((uintptr_t)a->q % 16) == 0 && ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0 &&
-                         ((uintptr_t)a->out % 8) == 0, "sprc_attention(bf16): misaligned pointer");
-        SPRC_REQUIRE(!two || (a->ldk2 % 8 == 0 && a->ldv2 % 8 == 0 && ((uintptr_t)a->k2 % 16) == 0 && ((uintptr_t)a->v2 % 16) == 0),
-                     "sprc_attention(bf16): second key segment misaligned");
-        const bool small = a->Tq <= 128;
-        // long query axes without a key mask (the ViT blocks): streaming kernel, four workgroups of three waves per CU (153 VGPRs)
-        // (SPRC_ATTN_STREAM=0 keeps the resident-K/V kernel for A/B runs)
-        static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
-        if (stream && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
-            static const int nw = [] { const char* e = getenv("SPRC_ATTN_WAVES"); return e ? atoi(e) : 3; }();
-            if (a->head_dim <= 64) return nw == 5 ? launch_stream<64, false, 5>(p, st) : nw == 9 ? launch_stream<64, false, 9>(p, st) : launch_stream<64, false, 3>(p, st);
-            if (a->head_dim == 88)                                             // denominator from the ones row of the padded V^T tile
-                return nw == 5 ? launch_stream<96, true, 5>(p, st) : nw == 9 ? launch_stream<96, true, 9>(p, st) : launch_stream<96, true, 3>(p, st);
-            return launch_stream<96, false, 3>(p, st);
-        }
-        // 257 tokens = 9 query tiles: nine waves (one tile each, the K / V staging shared by nine) beat eight waves of which
-        // one carries two tiles: 209 -> 195 us per ViT-g layer (SPRC_ATTN_NINE=0 for the A/B)
-        static const int nine = [] { const char* e = getenv("SPRC_ATTN_NINE"); return e ? atoi(e) : 1; }();
-        const int nqt = (a->Tq + 31) / 32;
-        if (nine && nqt == 9) {
-            if (a->head_dim <= 64) return launch_bf16<64, 9>(p, st);
-            return launch_bf16<96, 9>(p, st);
-        }
-        if (a->head_dim <= 64) return small ? launch_bf16<64, 4>(p, st) : launch_bf16<64, 8>(p, st);
-        return small ? launch_bf16<96, 4>(p, st) : launch_bf16<96, 8>(p, st);
-    }
+    if (a->dtype == SPRC_BF16) return attention16<false>(a, p, two, st);
+    if (a->dtype == SPRC_F16) return attention16<true>(a, p, two, st);
     SPRC_REQUIRE(a->dtype == SPRC_F32, "sprc_attention: bad dtype %d", a->dtype);
     SPRC_REQUIRE(Tk_all <= 64 * F32_MAXK, "sprc_attention(f32): Tk=%d > %d", Tk_all, 64 * F32_MAXK);
     SPRC_REQUIRE(a->head_dim % 4 == 0 && a->ldk % 4 == 0 && (!two || a->ldk2 % 4 == 0), "sprc_attention(f32): head_dim/ldk must be multiples of 4");

@@ -37,7 +37,9 @@ struct ProfScope {
 
 // ---- types -----------------------------------------------------------------------------------
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -54,6 +56,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {      // v_
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
     return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {       // RNE conversions, packed low | high
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    const f16x2_t v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+// two 16-bit operand values of the engine's compute dtype (F16: IEEE half, the reference's GPU autocast precision; else bf16)
+template <bool F16>
+__device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
+    if constexpr (F16) return pack_f16x2(lo, hi);
+    else return pack_bf16x2(lo, hi);
 }
 
 __host__ __device__ __forceinline__ int64_t map_row(const sprc_rowmap& m, int64_t r) {
@@ -75,6 +89,7 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
+static inline bool is16(int dt) { return dt == SPRC_BF16 || dt == SPRC_F16; }   // 16-bit MFMA operand engines
 static inline size_t dtype_size(int dt) { return dt == SPRC_FP8 ? 1 : (dt == SPRC_BF16 || dt == SPRC_F16) ? 2 : 4; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

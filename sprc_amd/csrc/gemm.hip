@@ -10,14 +10,14 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     using namespace sprc;
     SPRC_REQUIRE(a != nullptr, "sprc_gemm: null args");
     SPRC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "sprc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
-    SPRC_REQUIRE(a->dtype == SPRC_BF16 || a->dtype == SPRC_F32 || a->dtype == SPRC_FP8, "sprc_gemm: bad dtype %d", a->dtype);
+    SPRC_REQUIRE(a->dtype == SPRC_BF16 || a->dtype == SPRC_F16 || a->dtype == SPRC_F32 || a->dtype == SPRC_FP8, "sprc_gemm: bad dtype %d", a->dtype);
     SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32 || a->out_dtype == SPRC_F16 || a->out_dtype == SPRC_FP8,
                  "sprc_gemm: bad out_dtype %d", a->out_dtype);
     SPRC_REQUIRE(a->dtype != SPRC_FP8 || (a->w_scale != nullptr && a->a_scale > 0.f && !a->max32 && b == nullptr),
                  "sprc_gemm(fp8): needs w_scale, a_scale > 0; no max32 / paired launch");
     SPRC_REQUIRE(a->out_dtype != SPRC_FP8 || a->out_scale > 0.f, "sprc_gemm: SPRC_FP8 output needs out_scale > 0");
-    SPRC_REQUIRE(a->out_dtype != SPRC_F16 || (a->dtype == SPRC_BF16 && a->act == SPRC_ACT_NONE && !a->resid && !a->max32),
-                 "sprc_gemm: SPRC_F16 output takes bf16 operands and a plain (bias-only) epilogue");
+    SPRC_REQUIRE(a->out_dtype != SPRC_F16 || a->dtype == SPRC_F16 || (a->dtype == SPRC_BF16 && a->act == SPRC_ACT_NONE && !a->resid && !a->max32),
+                 "sprc_gemm: SPRC_F16 output takes fp16 operands, or bf16 operands and a plain (bias-only) epilogue");
     const int es = (int)dtype_size(a->dtype);
     SPRC_REQUIRE(((int64_t)a->K * es) % 128 == 0, "sprc_gemm: K=%d must be a multiple of %d", a->K, 128 / es);
     SPRC_REQUIRE((a->lda * es) % 16 == 0 && (a->ldw * es) % 16 == 0, "sprc_gemm: lda/ldw must be 16-byte multiples");
@@ -72,6 +72,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * a->K,
                    np * (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))));
     if (a->dtype == SPRC_FP8) return gemm_dispatch_fp8(a, p, st);
+    if (a->dtype == SPRC_F16) return gemm_dispatch_f16(a, p, st);
     return a->dtype == SPRC_BF16 ? gemm_dispatch_bf16(a, p, st) : gemm_dispatch_f32(a, p, st);
 }
 

@@ -75,7 +75,6 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-typedef _Float16 f16_t;
 struct fp8_t { uint8_t bits; };        // OCP e4m3fn (gfx950), operand / output tag type
 
 // saturating fp32 -> 2 x e4m3fn (v_cvt_pk_fp8_f32: RNE; inputs clamped to +-448 first, the format has no infinity)
@@ -109,6 +108,7 @@ __device__ __forceinline__ void store_out1(OutT* dst, float v) {
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<f16_t> { typedef f16x8 type; };
 template <> struct Frag<float> { typedef f32x4 type; };
 template <> struct Frag<fp8_t> { typedef u32x4 type; };       // unused: the fp8 main loop is the hand-pipelined one
 
@@ -154,14 +154,20 @@ __device__ __forceinline__ void wait_lgkmcnt() {
 // k-step 0 ((half ^ f(row)) << 4); k-step kk reads slot c0 ^ (kk << 5).
 // fp8 (FP8 = true): a 16-B fragment holds 16 k-values = TWO e4m3 MFMA k-steps (low / high 8 bytes); which bytes form a
 // k-step is a free permutation of k as long as both operands use the same one, so the LDS layout and the reads are the bf16 ones.
-__device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x16 c, std::false_type) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x16 c, std::true_type) {
-    const long b0 = (long)(((uint64_t)b[1] << 32) | b[0]), b1 = (long)(((uint64_t)b[3] << 32) | b[2]);
-    const long a0 = (long)(((uint64_t)a[1] << 32) | a[0]), a1 = (long)(((uint64_t)a[3] << 32) | a[2]);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b0, a0, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b1, a1, c, 0, 0, 0);
+// T = operand type of the 16-B fragments: bf16_t, f16_t (v_mfma_f32_32x32x16_f16: same rate, same fragment layout, 11-bit
+// significands -- the reference's own GPU precision, blip2.py:36-44) or fp8_t.
+template <typename T>
+__device__ __forceinline__ f32x16 mfma_frag(const u32x4& b, const u32x4& a, f32x16 c) {
+    if constexpr (std::is_same<T, fp8_t>::value) {
+        const long b0 = (long)(((uint64_t)b[1] << 32) | b[0]), b1 = (long)(((uint64_t)b[3] << 32) | b[2]);
+        const long a0 = (long)(((uint64_t)a[1] << 32) | a[0]), a1 = (long)(((uint64_t)a[3] << 32) | a[2]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b0, a0, c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b1, a1, c, 0, 0, 0);
+    } else if constexpr (std::is_same<T, f16_t>::value) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, b), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+    }
 }
 
 // MX-scaled e4m3 MFMA with unit block scales (E8M0 127 = 2^0): v_mfma_scale_f32_32x32x64_f8f6f4 covers K = 64 per instruction
@@ -230,7 +236,7 @@ __device__ __forceinline__ void pipe_ktile_mx(uint32_t a_base, uint32_t b_base, 
     });
 }
 
-template <int TM, int TN, int KT_BYTES, bool FP8, typename Issue>
+template <int TM, int TN, int KT_BYTES, typename T, typename Issue>
 __device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base, uint32_t c0, f32x16 (&acc)[TM][TN],
                                                 Issue&& issue) {
     static_assert(KT_BYTES == 128, "4 k-steps per K-tile");
@@ -255,7 +261,7 @@ __device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = mfma_frag(fb[cur][ni], fa[cur][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
+                acc[mi][ni] = mfma_frag<T>(fb[cur][ni], fa[cur][mi], acc[mi][ni]);
         __builtin_amdgcn_s_setprio(0);
     });
 }
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
                     if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
                 };
                 if constexpr (sizeof(T) == 1 && SPRC_FP8_MX) pipe_ktile_mx<TM, TN, KT_BYTES>(so + a_off, so + b_off, c0, acc, issue);
-                else pipe_ktile_bf16<TM, TN, KT_BYTES, sizeof(T) == 1>(so + a_off, so + b_off, c0, acc, issue);
+                else pipe_ktile_bf16<TM, TN, KT_BYTES, T>(so + a_off, so + b_off, c0, acc, issue);
             } else {
                 if (more) {
                     char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
@@ -635,10 +641,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //        G0 after C(t,1) (4t+3: B0 B1 of t+1) and after NC(t,0) (4t: A2 A3 of t); G1 after NC(t,1) (4t+3: A0 A1 B2 B3 of
 //        t+1).  Every piece has >= 2 intervals between issue and wait.
 //   WAR  a piece is restaged >= 1 interval after the barrier that followed the last read of the region it overwrites.
-template <typename OutT, int ACT, bool MAX32, bool STAMP = false, bool FP8 = false>
+template <typename T, typename OutT, int ACT, bool MAX32, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef typename std::conditional<FP8, fp8_t, bf16_t>::type T;
+    static_assert(sizeof(T) <= 2, "16-bit or fp8 operands");
+    constexpr bool FP8 = sizeof(T) == 1;
     constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
     constexpr int BM = 256, BN = 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         } else {
             static_for<0, 16>([&](auto x_) {
                 constexpr int x = decltype(x_)::value, k = x >> 3, mi = (x >> 1) & 3, ni = x & 1;
-                acc[mi][ni] = mfma_frag(fb[k][ni], fa[k][mi], acc[mi][ni], std::integral_constant<bool, FP8>{});
+                acc[mi][ni] = mfma_frag<T>(fb[k][ni], fa[k][mi], acc[mi][ni]);
                 if constexpr (x == (SPRC_ANTI_LDPOS)) { if (ld) load_piece(q_, I1{}, par_bytes, tile); }
             });
         }
@@ -981,11 +988,10 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
 template <typename T, typename OutT, int ACT, bool MAX32>
 static int launch_anti(GemmParams p, hipStream_t st) {
     constexpr int LDS = 2 * 512 * 128;
-    constexpr bool FP8 = sizeof(T) == 1;
-    auto kern = gemm_anti_kernel<OutT, ACT, MAX32, false, FP8>;
-    if constexpr (std::is_same<OutT, bf16_t>::value && ACT == SPRC_ACT_NONE && !MAX32 && !FP8) {
+    auto kern = gemm_anti_kernel<T, OutT, ACT, MAX32, false>;
+    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<OutT, bf16_t>::value && ACT == SPRC_ACT_NONE && !MAX32) {
         if ((p.debug & 64) && p.resid != nullptr) {         // phase-timestamp build (tools/gemm_stamp.py)
-            auto sk = gemm_anti_kernel<OutT, ACT, MAX32, true>;
+            auto sk = gemm_anti_kernel<T, OutT, ACT, MAX32, true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
             p.tiles_m = (p.M + 255) / 256;
             p.tiles_n = (p.N + 255) / 256;
@@ -1121,9 +1127,10 @@ static int launch(const GemmParams& p, hipStream_t st) {
 template <typename T>
 static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st) {
     if constexpr (sizeof(T) != 1) { if (a->max32) return launch<T, float, SPRC_ACT_NONE, true>(p, st); }
-    if (a->out_dtype == SPRC_F16) {                     // residual-branch delta (validated by the caller: bf16 operands, plain epilogue)
-        if constexpr (sizeof(T) == 2) return launch<T, f16_t, SPRC_ACT_NONE, false>(p, st);
-        else { set_error("sprc_gemm: SPRC_F16 output needs bf16 operands"); return SPRC_EUNSUPPORTED; }
+    if constexpr (std::is_same<T, bf16_t>::value) {     // residual-branch delta (validated by the caller: plain epilogue)
+        if (a->out_dtype == SPRC_F16) return launch<T, f16_t, SPRC_ACT_NONE, false>(p, st);
+    } else if constexpr (!std::is_same<T, f16_t>::value) {
+        if (a->out_dtype == SPRC_F16) { set_error("sprc_gemm: SPRC_F16 output needs bf16 or fp16 operands"); return SPRC_EUNSUPPORTED; }
     }
     if constexpr (sizeof(T) == 1) {                     // fp8 operands: the three epilogues of the fp8 ViT path
         if (a->out_dtype == SPRC_FP8) {
@@ -1140,14 +1147,21 @@ static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st
     } else {
         if (a->out_dtype == SPRC_FP8) { set_error("sprc_gemm: SPRC_FP8 output needs fp8 operands"); return SPRC_EUNSUPPORTED; }
     }
-    const bool o16 = a->out_dtype == SPRC_BF16;
+    // 16-bit output type of this operand type: fp16 operands write fp16, everything else bf16
+    constexpr bool H = std::is_same<T, f16_t>::value;
+    typedef typename std::conditional<H, f16_t, bf16_t>::type O16;
+    if (a->out_dtype != SPRC_F32 && a->out_dtype != (H ? SPRC_F16 : SPRC_BF16)) {
+        set_error("sprc_gemm: out_dtype %d does not go with operand dtype %d", a->out_dtype, a->dtype);
+        return SPRC_EUNSUPPORTED;
+    }
+    const bool o16 = a->out_dtype != SPRC_F32;
     switch (a->act) {
         case SPRC_ACT_NONE:
-            return o16 ? launch<T, bf16_t, SPRC_ACT_NONE, false>(p, st) : launch<T, float, SPRC_ACT_NONE, false>(p, st);
+            return o16 ? launch<T, O16, SPRC_ACT_NONE, false>(p, st) : launch<T, float, SPRC_ACT_NONE, false>(p, st);
         case SPRC_ACT_GELU:
-            return o16 ? launch<T, bf16_t, SPRC_ACT_GELU, false>(p, st) : launch<T, float, SPRC_ACT_GELU, false>(p, st);
+            return o16 ? launch<T, O16, SPRC_ACT_GELU, false>(p, st) : launch<T, float, SPRC_ACT_GELU, false>(p, st);
         case SPRC_ACT_QUICKGELU:
-            return o16 ? launch<T, bf16_t, SPRC_ACT_QUICKGELU, false>(p, st)
+            return o16 ? launch<T, O16, SPRC_ACT_QUICKGELU, false>(p, st)
                        : launch<T, float, SPRC_ACT_QUICKGELU, false>(p, st);
     }
     set_error("sprc_gemm: unknown activation %d", a->act);
@@ -1157,6 +1171,7 @@ static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st
 
 // per-operand-type dispatchers, one translation unit each
 int gemm_dispatch_bf16(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);
+int gemm_dispatch_f16(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);
 int gemm_dispatch_f32(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);
 int gemm_dispatch_fp8(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);
 

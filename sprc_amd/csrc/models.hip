@@ -144,7 +144,7 @@ static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& 
     const size_t es = dtype_size(m->dtype);
     const size_t S = (size_t)m->num_query + m->max_txt, R = (size_t)B * S, Hd = m->hidden;
     const size_t E = (size_t)B * enc_tokens;
-    q.enc = (with_kv && m->dtype == SPRC_BF16) ? b.take(E * m->enc_width * es) : nullptr;
+    q.enc = (with_kv && is16(m->dtype)) ? b.take(E * m->enc_width * es) : nullptr;
     q.kv = with_kv ? b.take(E * (size_t)m->n_cross * 2 * Hd * es) : nullptr;
     q.h32 = (float*)b.take(R * Hd * 4); q.h16 = b.take(R * Hd * es);
     q.a32 = (float*)b.take(R * Hd * 4); q.a16 = b.take(R * Hd * es);
@@ -262,8 +262,8 @@ static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, void* enc16
                         int enc_tokens) {
     const int E = B * enc_tokens;
     const void* enc = enc32;
-    if (m->dtype == SPRC_BF16) {
-        RUN(sprc_cast_f32_to_bf16(enc32, (uint16_t*)enc16, (size_t)E * m->enc_width, st));
+    if (is16(m->dtype)) {
+        RUN(sprc_cast_f32_to_16(enc32, enc16, (size_t)E * m->enc_width, m->dtype, st));
         enc = enc16;
     }
     const int Nkv = m->n_cross * 2 * m->hidden;
@@ -272,7 +272,7 @@ static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, void* enc16
 
 static int check_qf(const sprc_qformer_model* m) {
     SPRC_REQUIRE(m && m->layers, "qformer: null model");
-    SPRC_REQUIRE(m->dtype == SPRC_BF16 || m->dtype == SPRC_F32, "qformer: bad dtype");
+    SPRC_REQUIRE(is16(m->dtype) || m->dtype == SPRC_F32, "qformer: bad dtype");
     SPRC_REQUIRE(m->hidden == m->heads * m->head_dim, "qformer: hidden != heads*head_dim");
     SPRC_REQUIRE((m->num_query & (m->num_query - 1)) == 0 && (m->max_txt & (m->max_txt - 1)) == 0,
                  "qformer: num_query and max_txt must be powers of two");
@@ -301,7 +301,7 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
                                 size_t ws_bytes, sprc_stream s) {
     SPRC_REQUIRE(m && m->layers && images && raw && ws, "sprc_vit_forward: null pointer");
     SPRC_REQUIRE(B > 0, "sprc_vit_forward: B=%d", B);
-    SPRC_REQUIRE(m->dtype == SPRC_BF16 || m->dtype == SPRC_F32, "sprc_vit_forward: bad dtype");
+    SPRC_REQUIRE(is16(m->dtype) || m->dtype == SPRC_F32, "sprc_vit_forward: bad dtype");
     SPRC_REQUIRE(m->width == m->heads * m->head_dim, "sprc_vit_forward: width != heads*head_dim");
     SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_vit_forward: workspace must be 256-byte aligned");
     Bump b(ws, ws_bytes);
@@ -327,7 +327,7 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     // is ordered after `s` up to here and joined back into `s` before returning, so the call keeps its in-stream semantics.
     // Off by default: with kernels of two streams sharing the chip a per-kernel duration no longer measures the kernel.
     static const int n_streams = [] { const char* e = getenv("SPRC_VIT_STREAMS"); return e ? atoi(e) : 1; }();
-    const bool split = n_streams >= 2 && B >= 16 && dt == SPRC_BF16;
+    const bool split = n_streams >= 2 && B >= 16 && is16(dt);
     const int B0 = split ? B / 2 : B;
     hipStream_t st2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -548,14 +548,14 @@ extern "C" int sprc_qformer_text_only(const sprc_qformer_model* m, const float* 
 // ---- stage-2 rerank: blip2_qformer_cir_rerank.py:399-445 ------------------------------------------
 extern "C" size_t sprc_qformer_kv_workspace_bytes(const sprc_qformer_model* m, int32_t B, int32_t tokens) {
     if (!m || B <= 0 || tokens <= 0) return 0;
-    return (m->dtype == SPRC_BF16 ? (size_t)B * tokens * m->enc_width * 2 : 0) + 512;
+    return (is16(m->dtype) ? (size_t)B * tokens * m->enc_width * 2 : 0) + 512;
 }
 
 extern "C" int sprc_qformer_encode_kv(const sprc_qformer_model* m, const float* raw, int32_t B, int32_t tokens, void* kv,
                                       void* ws, size_t ws_bytes, sprc_stream s) {
     RUN(check_qf(m));
     SPRC_REQUIRE(raw && kv && B > 0 && tokens > 0, "sprc_qformer_encode_kv: bad arguments");
-    SPRC_REQUIRE(m->dtype != SPRC_BF16 || (ws && ((uintptr_t)ws % 256) == 0 && ws_bytes >= sprc_qformer_kv_workspace_bytes(m, B, tokens) - 512),
+    SPRC_REQUIRE(!is16(m->dtype) || (ws && ((uintptr_t)ws % 256) == 0 && ws_bytes >= sprc_qformer_kv_workspace_bytes(m, B, tokens) - 512),
                  "sprc_qformer_encode_kv: workspace too small or misaligned");
     SPRC_REQUIRE(((uintptr_t)kv % 16) == 0, "sprc_qformer_encode_kv: kv must be 16-byte aligned");
     return qf_encode_kv(m, (hipStream_t)s, ws, kv, raw, B, tokens);

@@ -51,7 +51,8 @@ __device__ __forceinline__ void layernorm_regs(RowRegs& r, int nch, int D, int l
     }
 }
 
-template <bool OUT16_IS_BF16>
+// KIND: the operand copy's type -- 0 fp32, 1 bf16, 2 fp16 (SPRC_F32 / SPRC_BF16 / SPRC_F16)
+template <int KIND>
 __device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y16, int nch, int lane) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -59,10 +60,10 @@ __device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y1
         if (i < nch) {
             if (y32) reinterpret_cast<float4*>(y32)[i] = r.v[c];
             if (y16) {
-                if constexpr (OUT16_IS_BF16) {
+                if constexpr (KIND != 0) {
                     uint2 pk;
-                    pk.x = pack_bf16x2(r.v[c].x, r.v[c].y);
-                    pk.y = pack_bf16x2(r.v[c].z, r.v[c].w);
+                    pk.x = pack16x2<KIND == 2>(r.v[c].x, r.v[c].y);
+                    pk.y = pack16x2<KIND == 2>(r.v[c].z, r.v[c].w);
                     reinterpret_cast<uint2*>(y16)[i] = pk;
                 } else {
                     reinterpret_cast<float4*>(y16)[i] = r.v[c];
@@ -95,7 +96,7 @@ __device__ __forceinline__ void add_row_f16(RowRegs& r, const _Float16* a, int n
     }
 }
 
-template <bool BF16>
+template <int KIND>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -106,12 +107,12 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams
     load_row(r, p.x + xr * p.ldx, nch, lane);
     if (p.add != nullptr) {
         add_row_f16(r, p.add + xr * p.ld_add, nch, lane);
-        if (p.sum32 != nullptr) store_row<false>(r, p.sum32 + xr * p.ld_sum, nullptr, nch, lane);
+        if (p.sum32 != nullptr) store_row<0>(r, p.sum32 + xr * p.ld_sum, nullptr, nch, lane);
     }
     layernorm_regs(r, nch, p.D, lane, p.gamma, p.beta, p.eps);
     const int64_t yr = map_row(p.ymap, row);
-    store_row<BF16>(r, p.y32 ? p.y32 + yr * p.ld32 : nullptr,
-                    p.y16 ? (char*)p.y16 + yr * p.ld16 * (BF16 ? 2 : 4) : nullptr, nch, lane);
+    store_row<KIND>(r, p.y32 ? p.y32 + yr * p.ld32 : nullptr,
+                    p.y16 ? (char*)p.y16 + yr * p.ld16 * (KIND ? 2 : 4) : nullptr, nch, lane);
 }
 
 // LayerNorm whose operand copy is e4m3fn: y8 = sat(LN(x) * q_scale)  (q_scale = 1 / the consumer GEMM's a_scale)
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_fp8_kernel(LnPa
     load_row(r, p.x + xr * p.ldx, nch, lane);
     layernorm_regs(r, nch, p.D, lane, p.gamma, p.beta, p.eps);
     const int64_t yr = map_row(p.ymap, row);
-    if (p.y32) store_row<false>(r, p.y32 + yr * p.ld32, nullptr, nch, lane);
+    if (p.y32) store_row<0>(r, p.y32 + yr * p.ld32, nullptr, nch, lane);
     uint32_t* y8 = reinterpret_cast<uint32_t*>((char*)p.y16 + yr * p.ld16);
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t* __rest
     if ((threadIdx.x & 63) == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
 }
 
-template <bool BF16>
+template <int KIND>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc_qformer_embed_args p) {
     const int lane = threadIdx.x & 63;
     const int S = p.Lq + p.Lt;
@@ -200,11 +201,11 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc
         }
     }
     layernorm_regs(r, nch, p.hidden, lane, p.gamma, p.beta, p.eps);
-    store_row<BF16>(r, p.y32 ? p.y32 + (int64_t)row * p.hidden : nullptr,
-                    p.y16 ? (char*)p.y16 + (int64_t)row * p.hidden * (BF16 ? 2 : 4) : nullptr, nch, lane);
+    store_row<KIND>(r, p.y32 ? p.y32 + (int64_t)row * p.hidden : nullptr,
+                    p.y16 ? (char*)p.y16 + (int64_t)row * p.hidden * (KIND ? 2 : 4) : nullptr, nch, lane);
 }
 
-template <bool BF16>
+template <int KIND>
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void l2norm_kernel(const float* x, int64_t ldx, float* y32, void* y16,
                                                                      int64_t ldy, int M, int D) {
     const int lane = threadIdx.x & 63;
@@ -219,26 +220,27 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void l2norm_kernel(const float
     const float inv = 1.0f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);       // F.normalize: x / max(||x||, eps)
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) { r.v[c].x *= inv; r.v[c].y *= inv; r.v[c].z *= inv; r.v[c].w *= inv; }
-    store_row<BF16>(r, y32 ? y32 + (int64_t)row * ldy : nullptr,
-                    y16 ? (char*)y16 + (int64_t)row * ldy * (BF16 ? 2 : 4) : nullptr, nch, lane);
+    store_row<KIND>(r, y32 ? y32 + (int64_t)row * ldy : nullptr,
+                    y16 ? (char*)y16 + (int64_t)row * ldy * (KIND ? 2 : 4) : nullptr, nch, lane);
 }
 
+template <bool F16>
 __global__ void cast_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         const float4 v = reinterpret_cast<const float4*>(src)[i];
         uint2 pk;
-        pk.x = pack_bf16x2(v.x, v.y);
-        pk.y = pack_bf16x2(v.z, v.w);
+        pk.x = pack16x2<F16>(v.x, v.y);
+        pk.y = pack16x2<F16>(v.z, v.w);
         reinterpret_cast<uint2*>(dst)[i] = pk;
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        dst[i] = f32_to_bf16_bits(src[i]);
+        dst[i] = (uint16_t)(pack16x2<F16>(src[i], 0.f) & 0xffffu);
 }
 
 // rows[(b*G*G + py*G + px), k] = image[b, c, py*P + i, px*P + j],  k = c*P*P + i*P + j  (zero for k >= 3*P*P)
-template <bool BF16>
+template <int KIND>
 __global__ void im2row_kernel(const float* __restrict__ img, void* __restrict__ rows, int B, int S, int P, int kpad) {
     const int G = S / P, PP = P * P, kreal = 3 * PP;
     const int64_t total = (int64_t)B * G * G * kpad;
@@ -253,7 +255,7 @@ __global__ void im2row_kernel(const float* __restrict__ img, void* __restrict__ 
             const int64_t b = row / (G * G);
             v = img[((b * 3 + c) * S + (py * P + i)) * (int64_t)S + (px * P + j)];
         }
-        if constexpr (BF16) reinterpret_cast<uint16_t*>(rows)[e] = f32_to_bf16_bits(v);
+        if constexpr (KIND != 0) reinterpret_cast<uint16_t*>(rows)[e] = (uint16_t)(pack16x2<KIND == 2>(v, 0.f) & 0xffffu);
         else reinterpret_cast<float*>(rows)[e] = v;
     }
 }
@@ -290,13 +292,20 @@ static int grid_for(int64_t n, int block, int cap = 256 * 8) {
 
 using namespace sprc;
 
-extern "C" int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s) {
-    SPRC_REQUIRE(src && dst, "sprc_cast_f32_to_bf16: null pointer");
+extern "C" int sprc_cast_f32_to_16(const float* src, void* dst, size_t n, int32_t dtype, sprc_stream s) {
+    SPRC_REQUIRE(src && dst, "sprc_cast_f32_to_16: null pointer");
+    SPRC_REQUIRE(is16(dtype), "sprc_cast_f32_to_16: dtype %d is not a 16-bit type", dtype);
     if (n == 0) return SPRC_OK;
-    SPRC_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "sprc_cast_f32_to_bf16: misaligned");
-    hipLaunchKernelGGL(cast_kernel, dim3(grid_for((int64_t)(n / 4 + 1), 256)), dim3(256), 0, (hipStream_t)s, src, dst, n);
-    SPRC_CHECK_LAUNCH("sprc_cast_f32_to_bf16");
+    SPRC_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "sprc_cast_f32_to_16: misaligned");
+    const dim3 grid(grid_for((int64_t)(n / 4 + 1), 256)), block(256);
+    if (dtype == SPRC_F16) hipLaunchKernelGGL(cast_kernel<true>, grid, block, 0, (hipStream_t)s, src, reinterpret_cast<uint16_t*>(dst), n);
+    else hipLaunchKernelGGL(cast_kernel<false>, grid, block, 0, (hipStream_t)s, src, reinterpret_cast<uint16_t*>(dst), n);
+    SPRC_CHECK_LAUNCH("sprc_cast_f32_to_16");
     return SPRC_OK;
+}
+
+extern "C" int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s) {
+    return sprc_cast_f32_to_16(src, dst, n, SPRC_BF16, s);
 }
 
 extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
@@ -318,8 +327,9 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
         SPRC_REQUIRE(a->y16 != nullptr && a->y16_scale > 0.f && a->add16 == nullptr && ((uintptr_t)a->y16 % 4) == 0,
                      "sprc_layernorm(fp8): needs y16, y16_scale > 0 and no fused add");
         hipLaunchKernelGGL(layernorm_fp8_kernel, grid, block, 0, (hipStream_t)s, p, a->y16_scale);
-    } else if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<true>, grid, block, 0, (hipStream_t)s, p);
-    else hipLaunchKernelGGL(layernorm_kernel<false>, grid, block, 0, (hipStream_t)s, p);
+    } else if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, (hipStream_t)s, p);
+    else if (a->out_dtype == SPRC_F16) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, (hipStream_t)s, p);
+    else hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, (hipStream_t)s, p);
     SPRC_CHECK_LAUNCH("sprc_layernorm");
     return SPRC_OK;
 }
@@ -451,8 +461,9 @@ extern "C" int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream 
     SPRC_REQUIRE(a->hidden % 4 == 0 && a->hidden <= 64 * 4 * MAXC, "sprc_qformer_embed: hidden=%d unsupported", a->hidden);
     const int rows = a->B * (a->Lq + a->Lt);
     const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
-    if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(qformer_embed_kernel<true>, grid, block, 0, (hipStream_t)s, *a);
-    else hipLaunchKernelGGL(qformer_embed_kernel<false>, grid, block, 0, (hipStream_t)s, *a);
+    if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(qformer_embed_kernel<1>, grid, block, 0, (hipStream_t)s, *a);
+    else if (a->out_dtype == SPRC_F16) hipLaunchKernelGGL(qformer_embed_kernel<2>, grid, block, 0, (hipStream_t)s, *a);
+    else hipLaunchKernelGGL(qformer_embed_kernel<0>, grid, block, 0, (hipStream_t)s, *a);
     SPRC_CHECK_LAUNCH("sprc_qformer_embed");
     return SPRC_OK;
 }
@@ -462,8 +473,9 @@ extern "C" int sprc_l2norm_rows(const float* x, int64_t ldx, float* y32, void* y
     SPRC_REQUIRE(x && (y32 || y16), "sprc_l2norm_rows: null pointer");
     SPRC_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC && ldx % 4 == 0 && ldy % 4 == 0, "sprc_l2norm_rows: bad shape");
     const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
-    if (out_dtype == SPRC_BF16) hipLaunchKernelGGL(l2norm_kernel<true>, grid, block, 0, (hipStream_t)s, x, ldx, y32, y16, ldy, M, D);
-    else hipLaunchKernelGGL(l2norm_kernel<false>, grid, block, 0, (hipStream_t)s, x, ldx, y32, y16, ldy, M, D);
+    if (out_dtype == SPRC_BF16) hipLaunchKernelGGL(l2norm_kernel<1>, grid, block, 0, (hipStream_t)s, x, ldx, y32, y16, ldy, M, D);
+    else if (out_dtype == SPRC_F16) hipLaunchKernelGGL(l2norm_kernel<2>, grid, block, 0, (hipStream_t)s, x, ldx, y32, y16, ldy, M, D);
+    else hipLaunchKernelGGL(l2norm_kernel<0>, grid, block, 0, (hipStream_t)s, x, ldx, y32, y16, ldy, M, D);
     SPRC_CHECK_LAUNCH("sprc_l2norm_rows");
     return SPRC_OK;
 }
@@ -473,8 +485,9 @@ extern "C" int sprc_im2row(const float* images, void* rows, int32_t B, int32_t i
     SPRC_REQUIRE(images && rows, "sprc_im2row: null pointer");
     SPRC_REQUIRE(B > 0 && patch > 0 && image % patch == 0 && k_pad >= 3 * patch * patch, "sprc_im2row: bad shape");
     const int64_t total = (int64_t)B * (image / patch) * (image / patch) * k_pad;
-    if (dtype == SPRC_BF16) hipLaunchKernelGGL(im2row_kernel<true>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
-    else hipLaunchKernelGGL(im2row_kernel<false>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
+    if (dtype == SPRC_BF16) hipLaunchKernelGGL(im2row_kernel<1>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
+    else if (dtype == SPRC_F16) hipLaunchKernelGGL(im2row_kernel<2>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
+    else hipLaunchKernelGGL(im2row_kernel<0>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
     SPRC_CHECK_LAUNCH("sprc_im2row");
     return SPRC_OK;
 }

@@ -15,6 +15,7 @@ from . import _lib as L
 from .config import SprcConfig
 
 _TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16, L.SPRC_F16: torch.float16, L.SPRC_FP8: torch.float8_e4m3fn}
+_SPRC_DT = {v: k for k, v in _TORCH_DT.items()}
 FP8_MAX = 448.0                                   # largest finite e4m3fn
 
 
@@ -44,7 +45,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None
          M=None, amap=None, cmap=None, ldc=None, scratch=None, w_scale=None, a_scale=0.0, out_scale=0.0) -> torch.Tensor:
     """fp8 operands (torch.float8_e4m3fn A and W): w_scale [N] fp32, a_scale; out_dtype SPRC_FP8 also needs out_scale."""
     lib = L.load()
-    dt = L.SPRC_BF16 if A.dtype == torch.bfloat16 else L.SPRC_FP8 if A.dtype == torch.float8_e4m3fn else L.SPRC_F32
+    dt = _SPRC_DT[A.dtype]
     assert W.dtype == A.dtype and A.is_cuda and A.stride(-1) == 1 and W.stride(-1) == 1
     N, K = W.shape
     M = A.shape[0] if M is None else M
@@ -70,7 +71,7 @@ def gemm_pair(A: torch.Tensor, W0: torch.Tensor, W1: torch.Tensor, bias0, bias1,
     """Two products of identical shape in one launch (sprc_gemm_pair): rows amap0 of A through W0 into rows cmap0 of `out`,
     rows amap1 through W1 into rows cmap1."""
     lib = L.load()
-    dt = L.SPRC_BF16 if A.dtype == torch.bfloat16 else L.SPRC_F32
+    dt = _SPRC_DT[A.dtype]
     N, K = W0.shape
     odt = dt if out_dtype is None else out_dtype
     gs = []
@@ -116,7 +117,7 @@ def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=No
     """k2 / v2 (optional): a second key segment of Tk2 tokens appended to the key axis; kv_index / kv2_index: int32 [B] batch
     rows of the two segments (see sprc_attention_args)."""
     lib = L.load()
-    dt = L.SPRC_BF16 if q.dtype == torch.bfloat16 else L.SPRC_F32
+    dt = _SPRC_DT[q.dtype]
     if out is None:
         out = torch.empty((B * Tq, H * head_dim), dtype=q.dtype, device=q.device)
     a = L.AttentionArgs()
@@ -137,7 +138,7 @@ def sim_max(fusion: torch.Tensor, feats: torch.Tensor, out: Optional[torch.Tenso
     nq, E = fusion.shape
     N, J, E2 = feats.shape
     assert J == 32 and E2 == E and fusion.dtype == feats.dtype and fusion.is_contiguous() and feats.is_contiguous()
-    dt = L.SPRC_BF16 if fusion.dtype == torch.bfloat16 else L.SPRC_F32
+    dt = _SPRC_DT[fusion.dtype]
     if out is None:
         out = torch.empty((nq, N), dtype=torch.float32, device=fusion.device)
     L.check(lib.sprc_sim_max(fusion.data_ptr(), feats.data_ptr(), out.data_ptr(), out.stride(0), nq, N, E, dt, _stream()),
@@ -203,6 +204,7 @@ class Engine:
                 raise ValueError(f"the fp8 engine needs fp8_amax [{cfg.vit.depth}, 3] from Engine.calibrate_fp8")
             self._act_scale = (fp8_amax.detach().float().cpu().clamp_min(1e-6) * fp8_margin / FP8_MAX).tolist()
         self.dt = L.DTYPES[dtype]
+        self.is16 = L.is16(self.dt)               # bf16 or fp16 MFMA operands (fp32 accumulate / residual stream / LN / softmax)
         self.tdt = _TORCH_DT[self.dt]
         self.max_batch = max_batch
         self._keep: List[torch.Tensor] = []
@@ -237,7 +239,7 @@ class Engine:
         v = self.cfg.vit
         p = "visual_encoder."
         D = v.width
-        kq = 64 if self.dt == L.SPRC_BF16 else 32
+        kq = 64 if self.is16 else 32
         self.patch_k_pad = (v.patch_k + kq - 1) // kq * kq
         layers = (L.VitLayer * v.depth)()
         for i in range(v.depth):
@@ -386,7 +388,7 @@ class Engine:
             raise ValueError(f"raw embeddings must be [B, {self.cfg.vit.tokens}, {self.cfg.vit.width}], got {tuple(raw.shape)}")
         B, E, Lq = raw.shape[0], self.cfg.embed_dim, self.cfg.qformer.num_query
         feats = torch.empty((B, Lq, E), dtype=torch.float32, device=self.device)
-        f16 = torch.empty((B, Lq, E), dtype=self.tdt, device=self.device) if self.dt == L.SPRC_BF16 else None
+        f16 = torch.empty((B, Lq, E), dtype=self.tdt, device=self.device) if self.is16 else None
         for s in range(0, B, self.max_batch):
             n = min(self.max_batch, B - s)
             ws = self._workspace("qf", n)
@@ -409,7 +411,7 @@ class Engine:
         if not input_ids.is_cuda and (int(input_ids.min()) < 0 or int(input_ids.max()) >= self.cfg.qformer.vocab):
             raise IndexError("token id out of range")       # device-resident ids are clamped by the kernel (no host sync)
         fusion = torch.empty((B, E), dtype=torch.float32, device=self.device)
-        f16 = torch.empty((B, E), dtype=self.tdt, device=self.device) if self.dt == L.SPRC_BF16 else None
+        f16 = torch.empty((B, E), dtype=self.tdt, device=self.device) if self.is16 else None
         for s in range(0, B, self.max_batch):
             n = min(self.max_batch, B - s)
             ws = self._workspace("qf", n)
