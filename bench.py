@@ -34,6 +34,11 @@ Q_PER_STEP = (BATCH * QUERIES + GALLERY - 1) // GALLERY          # 233 -> keep C
 MFMA_BF16_PEAK_TFLOPS = 2500.0                                    # dense bf16, MI355X_MICROARCH.md
 MFMA_FP8_PEAK_TFLOPS = 5000.0                                     # dense fp8 (MX-scaled K = 128 / 64 instructions), same table
 HBM_PEAK_GBS = 8000.0
+# ALGORITHMIC work per unit (BASELINE.md section 4 / SURVEY.md section 8(d); 1 MAC = 2 FLOP): what `roofline.step_frac` prices a
+# whole step with -- extra MFMA work an implementation chooses to do (the split-precision Q-Former's lo terms) does not count
+GFLOP_PER_IMAGE = {"pretrain": 533.4, "pretrain_vitL": 166.2}
+GFLOP_PER_QUERY = {"pretrain": 29.3, "pretrain_vitL": 27.5}
+FLOP_PER_PAIR = 16384.0
 # the GEMM class = every launch of these kernels (sprc_amd/csrc/gemm.hip); the 256x256 anti-phase kernel carries > 95 % of
 # the class time at the bench shapes, the 128x128 kernel the remainder rows and the small Q-Former products
 GEMM_KERNELS = {"fp16": "sprc::gemm_anti_kernel<f16,...> (256x256 anti-phase, v_mfma_f32_32x32x16_f16, dominant) + sprc::gemm_kernel<f16,...> (128x128 / 64x64)",
@@ -58,7 +63,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp8"], help="fp16: fp16 MFMA operands (the reference's GPU autocast precision; the bf16 rate); fp8: bf16 engine whose ViT qkv / fc1 / fc2 GEMMs run on e4m3fn operands (BASELINE config C5)")
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp8"], help="fp16: fp16 MFMA operands (the reference's GPU autocast precision; the bf16 rate); fp8: bf16 engine whose ViT qkv / fc1 / fc2 GEMMs run on e4m3fn operands (BASELINE config C5)")
     ap.add_argument("--backbone", default="pretrain", choices=["pretrain", "pretrain_vitL"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=10, help="record per-launch HIP events on every Nth timed step, starting with the first (0 = never)")
@@ -90,6 +95,14 @@ def cpu_baseline(cfg, n_img: int):
     sd = synth.make_state_dict(cfg, seed=0)
     images = synth.make_images(n_img, seed=0)
     nq = 2 * n_img
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     ids, mask, ref = synth.make_queries(nq, n_img, seed=1)
     with torch.no_grad():
         O.extract_target_features(sd, cfg, images[:1])             # warm-up (thread pools, page-in)
@@ -101,9 +114,12 @@ def cpu_baseline(cfg, n_img: int):
         t2 = time.perf_counter()
     # scale the query side to the workload's ratio (QUERIES/GALLERY queries per image)
     per_img = (t1 - t0) / n_img + (t2 - t1) / nq * (QUERIES / GALLERY)
-    return {"value": round(1.0 / per_img, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 (torch CPU, {cores} threads): encode {n_img} images {t1 - t0:.1f}s + fuse/rank {nq} queries "
-                      f"{t2 - t1:.1f}s, query cost scaled to {QUERIES}/{GALLERY} queries per image"}
+    return {"value": round(1.0 / per_img, 4), "unit": "images/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+            "encode_images_per_s": round(n_img / (t1 - t0), 4), "fuse_rank_queries_per_s": round(nq / (t2 - t1), 3),
+            "sample": f"BOUNDED sample, one pass after a one-image warm-up (SURVEY 8(d) plans 256 images / 64 queries, best of 3: ~11 min "
+                      f"of CPU time, outside the bench's budget): oracle fp32 (torch CPU, {cores} threads on {cpu_model}): encode {n_img} "
+                      f"images {t1 - t0:.1f}s + fuse/rank {nq} queries vs {n_img} images {t2 - t1:.1f}s; value = 1 / (s per image + "
+                      f"{QUERIES}/{GALLERY} x s per query)"}
 
 
 def respawn(n: int) -> int:
@@ -254,6 +270,14 @@ def main():
                 traffic = round(tr["gemm_bytes_per_step"]["total"] / (pe.launches / n_prof), 1)
                 traffic_src = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only "
                                "passes over this command on this build: kernel_source_sha %s)" % tr["kernel_source_sha"][:12])
+        # whole-step utilisation: ALGORITHMIC flops of one step over the step time, against the dtype's peak
+        step_tflop = (BATCH * GFLOP_PER_IMAGE[a.backbone] + Q_PER_STEP * GFLOP_PER_QUERY[a.backbone]) * 1e-3 \
+            + Q_PER_STEP * GALLERY * FLOP_PER_PAIR * 1e-12
+        precision = {"fp16": "fp16 MFMA operands, fp32 accumulate / residual stream / LayerNorm / softmax; ViT fp16 as under the reference's "
+                             "autocast (blip2.py:36-44), Q-Former at split-precision (hi + lo fp16 operands, masks image %d / query %d) as the "
+                             "reference keeps it in fp32 (align_prompt.py:366-368)" % (eng.x3_image, eng.x3_fuse),
+                     "bf16": "bf16 MFMA operands, fp32 accumulate / residual stream / LayerNorm / softmax",
+                     "fp8": "bf16 engine, ViT qkv / fc1 / fc2 on e4m3 MX MFMA", "fp32": "exact fp32 MFMA"}[a.dtype]
         out = {
             "metric": "gallery images encoded+ranked/sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -263,9 +287,12 @@ def main():
                                    f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
                        "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams,
+                       "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and backend == "nccl" else None),
                        "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNELS[a.dtype], "achieved": round(ach, 1), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                         "step_frac": round(step_tflop / (dt / a.steps) / peak, 4), "step_alg_tflop": round(step_tflop, 2),
+                         "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch", "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(pe.bytes / max(pe.launches, 1), 1),
                          "launches": int(pe.launches), "avg_launch_ms": round(pe.busy_ms / max(pe.launches, 1), 4),

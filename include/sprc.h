@@ -37,6 +37,12 @@ enum { SPRC_F32 = 0, SPRC_BF16 = 1,
                        lavis/models/blip2_models/blip2.py:36-44, eva_vit.py:410-425), 8x finer operand rounding than bf16.
                        Also an OUTPUT dtype of a bf16 sprc_gemm: a residual-branch output ("delta") that sprc_layernorm
                        adds to the fp32 residual stream */,
+       SPRC_F16X3 = 4 /* STORAGE layout of split-precision fp16 activations (OUTPUT dtype of sprc_gemm / sprc_layernorm /
+                         sprc_qformer_embed / sprc_cast_f32_to_16 / sprc_attention.out_x3): a logical [M, K] matrix x is stored as
+                         [M, 3K] fp16 = [hi | lo | hi] with hi = fp16(x), lo = fp16(x - hi).  Multiplied (plain SPRC_F16 sprc_gemm,
+                         K' = 3K) with weights packed [W_hi | W_hi | W_lo] it yields x_hi.W_hi + x_lo.W_hi + x_hi.W_lo: the product
+                         to ~2^-21 instead of 2^-11 -- what lets the Q-Former of the fp16 engine follow the reference's GPU path,
+                         whose Q-Former runs in fp32 OUTSIDE the fp16 autocast (blip2_qformer_cir_align_prompt.py:366-368) */,
        SPRC_FP8 = 3 /* OCP e4m3fn (the gfx950 fp8; NOT MI300's fnuz): GEMM operands with a per-tensor activation scale and
                        per-output-channel weight scales, fp32 accumulation (BASELINE.json config C5: "ViT-L, fp8 MFMA") */ };
 enum { SPRC_ACT_NONE = 0, SPRC_ACT_GELU = 1, SPRC_ACT_QUICKGELU = 2 };
@@ -76,12 +82,14 @@ int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s);
 int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s);
 /* fp32 -> `dtype` (SPRC_BF16 or SPRC_F16), round-to-nearest-even. */
 int sprc_cast_f32_to_16(const float* src, void* dst, size_t n, int32_t dtype, sprc_stream s);
+/* fp32 [rows, cols] (contiguous) -> SPRC_F16X3 [rows, 3 cols]; cols % 4 == 0. */
+int sprc_cast_f32_to_x3(const float* src, void* dst, int64_t rows, int32_t cols, sprc_stream s);
 
 /* C = epilogue(A[M,K] . W[N,K]^T + bias) -- replaces every nn.Linear / F.linear on the path:
  * eva_vit.py:123,146,55-60; clip_vit.py:132-139; Qformer.py:135-137,201-211,291-293,365,377;
  * align_prompt.py:348,385.  A and W are `dtype`; bias/resid fp32; out is `out_dtype`.
  * K % 64 == 0 (bf16, fp16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (16-bit) / 4 (f32) elements.
- * dtype SPRC_F16: outputs fp16 or f32, every epilogue.
+ * dtype SPRC_F16: outputs fp16, f32 or SPRC_F16X3 (ldc >= 3 N, N % 4 == 0; no residual, no max32), every activation.
  * out_dtype SPRC_F16 with bf16 operands: no activation / residual / max32 (see sprc_layernorm_args.add16).
  * dtype SPRC_FP8: K % 128 == 0; outputs bf16 / f32 (plain epilogue, residual allowed) or fp8 (any activation).
  *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
@@ -120,7 +128,7 @@ typedef struct {
     const float* x;  int64_t ldx;  sprc_rowmap xmap;
     const float* gamma; const float* beta; float eps;
     float* y32;      int64_t ld32; sprc_rowmap ymap;
-    void*  y16;      int64_t ld16;              /* rows mapped with ymap as well */
+    void*  y16;      int64_t ld16;              /* rows mapped with ymap as well; out_dtype SPRC_F16X3: ld16 >= 3 D */
     /* Optional fused residual add (bf16 engine): the normalised row is x + add16, with add16 the fp16 output of the branch
      * GEMM (attention proj / MLP fc2 / BERT output.dense: eva_vit.py:178-179, clip_vit.py:137-138, Qformer.py:294,380).
      * The fp32 + residual GEMM epilogue it replaces was an un-overlapped HBM burst (8 B per element with the matrix pipe
@@ -156,6 +164,7 @@ typedef struct {
     const void* v2; int64_t ldv2;
     int32_t Tk2;
     const int32_t* kv_index; const int32_t* kv2_index;
+    int32_t out_x3;   /* dtype SPRC_F16 only: `out` is stored in the SPRC_F16X3 layout (logical width H * head_dim, ldo >= 3 H head_dim) */
 } sprc_attention_args;
 int sprc_attention(const sprc_attention_args* a, sprc_stream s);
 
@@ -178,7 +187,7 @@ typedef struct {
     const int64_t* input_ids;
     const float* word_emb; const float* pos_emb;
     const float* gamma; const float* beta; float eps;
-    float* y32; void* y16;                      /* [B, Lq+Lt, hidden] contiguous */
+    float* y32; void* y16;                      /* [B, Lq+Lt, hidden] contiguous ([.., 3 hidden] for out_dtype SPRC_F16X3) */
     int32_t no_img;                             /* 1: the text-only form of Qformer.py:88-104 (training, align_prompt.py:173-179): rows =
                                                  * [text[0] ; the Lq query rows ; text[1:]] and every row gets its absolute position */
 } sprc_qformer_embed_args;
@@ -217,6 +226,8 @@ int sprc_rank_of(const float* sim, int64_t ld, const int32_t* listed, int32_t nq
  * Composite forward passes (one call per batch; the kernels above, sequenced on `s`)
  * ---------------------------------------------------------------------------------------- */
 
+enum { SPRC_X3_QKV = 1, SPRC_X3_ATTN_OUT = 2, SPRC_X3_CROSS_Q = 4, SPRC_X3_CROSS_OUT = 8, SPRC_X3_FFN_IN = 16, SPRC_X3_FFN_OUT = 32,
+       SPRC_X3_CKV = 64, SPRC_X3_HEADS = 128, SPRC_X3_ALL = 255 };      /* layer kinds of sprc_qformer_model.x3 */
 typedef struct { const void* w; const float* b; } sprc_linear;   /* w: [out,in(padded)] compute dtype */
 
 typedef struct {
@@ -256,6 +267,12 @@ typedef struct {
     sprc_linear ckv_all;                        /* [n_cross*2*hidden, enc_width]: K|V of every cross layer */
     sprc_linear vision_proj, text_proj;         /* [embed_dim, hidden] */
     const sprc_qf_layer* layers;                /* host array [n_layers] */
+    int32_t x3;                                 /* != 0 (dtype SPRC_F16 only): split-precision Q-Former -- every GEMM input activation is
+                                                 * kept in the SPRC_F16X3 layout, and the weight matrices of the layer KINDS whose SPRC_X3_*
+                                                 * bit is set are packed [out, 3 in] = [W_hi | W_hi | W_lo] (the others stay [out, in] and
+                                                 * multiply the hi segment only); attention operands (q, k, v, probabilities) stay plain fp16 */
+    int32_t x3_image, x3_fuse;                  /* subsets of x3: the kinds that reduce over all three segments in sprc_qformer_image /
+                                                 * in the query-side calls (fuse, text_only, encode_kv, itm); the others read hi only */
 } sprc_qformer_model;
 
 /* Workspace sizes in bytes for a batch of B (images or queries). */
@@ -340,6 +357,12 @@ int sprc_qformer_fuse_train(const sprc_qformer_model* m, const float* ref_embeds
 int sprc_qformer_text_only(const sprc_qformer_model* m, const float* prompt_tokens, const int64_t* input_ids,
                            const int64_t* attention_mask, int32_t B, float* feat, void* feat16,
                            void* ws, size_t ws_bytes, sprc_stream s);
+
+/* feat[B,E] = normalize(text_proj(Qformer(text)[:, 0, :])): the Q-Former as a plain text encoder -- no query rows, no image, text FFN
+ * on every row (Qformer.py:98-114 with query_embeds None, :469-475).  This is the STAGE-1 score of the rerank model class,
+ * Blip2QformerCirRerank.inference (lavis/models/blip2_models/blip2_qformer_cir_rerank.py:373-397), which ignores the reference image. */
+int sprc_qformer_text(const sprc_qformer_model* m, const int64_t* input_ids, const int64_t* attention_mask, int32_t B,
+                      float* feat, void* feat16, void* ws, size_t ws_bytes, sprc_stream s);
 
 /* loss[0] = F.cross_entropy(sim[B,B] / temp, arange(B))  (:157-167, :181-190);  sim fp32, ld in elements. */
 int sprc_contrastive_ce(const float* sim, int64_t ld, int32_t B, float temp, float* loss, sprc_stream s);

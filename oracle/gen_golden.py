@@ -302,9 +302,14 @@ def rerank_goldens(out: Path, seed: int = 2):
         prob = model.inference_rerank(raw[ref], raw[cand.reshape(-1)], ["caption"] * n_q)
         model.tokenizer.set_next(ids[:1], mask[:1])
         prob_one = model.inference_rerank(raw[ref[:1]], raw[cand[0]], ["caption"])          # the B == 1 branch (:404-406)
+        # the rerank class's own STAGE-1 score (:373-397): text only, against the gallery features of the same model
+        feats, _ = model.extract_target_features(images, mode="mean")
+        model.tokenizer.set_next(ids, mask)
+        sim_stage1 = model.inference(raw[ref], feats, ["caption"] * n_q)
     np.savez_compressed(out, model_type="pretrain", vit_depth=2, seed=seed, n_img=n_img, n_q=n_q, T=T,
                         image_probe=_np(images[:, :, 0, :4]), input_ids=ids.numpy(), attention_mask=mask.numpy(),
-                        ref_index=ref.numpy(), cand_index=cand.numpy(), prob=_np(prob), prob_one=_np(prob_one))
+                        ref_index=ref.numpy(), cand_index=cand.numpy(), prob=_np(prob), prob_one=_np(prob_one),
+                        sim_stage1=_np(sim_stage1), feats=_np(feats))
     print(f"wrote {out}: prob {prob.numpy().round(4).tolist()}")
 
 

@@ -252,6 +252,29 @@ def inference(sd: SD, cfg, reference_embeds: Tensor, target_feats: Tensor, input
     return similarity(fusion, target_feats)
 
 
+def text_feature(sd: SD, cfg, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
+    """The query side of `Blip2QformerCirRerank.inference` (blip2_qformer_cir_rerank.py:373-390): `Qformer.bert(ids, mask)` with no
+    query tokens and no image -- word + position embeddings (positions from 0, Qformer.py:93-105), LayerNorm, 12 layers of
+    self-attention + TEXT FFN on every row (:469-475) -- then normalize(text_proj(h[:, 0, :]))."""
+    qc = cfg.qformer
+    p = "Qformer.bert."
+    S = input_ids.shape[1]
+    emb = sd[p + "embeddings.word_embeddings.weight"].float()[input_ids] \
+        + sd[p + "embeddings.position_embeddings.weight"].float()[:S].unsqueeze(0)
+    x = _ln(emb, sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], qc.ln_eps)
+    add_mask = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
+    for l in range(qc.layers):
+        b = f"{p}encoder.layer.{l}."
+        a = _bert_attention(sd, b + "attention.", x, x, add_mask, qc.heads, qc.ln_eps)
+        x = _bert_ffn(sd, b + "intermediate.", b + "output.", a, qc.ln_eps)
+    return _normalize(F.linear(x[:, 0, :], sd["text_proj.weight"].float(), sd["text_proj.bias"].float()))
+
+
+def inference_rerank_stage1(sd: SD, cfg, target_feats: Tensor, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
+    """`Blip2QformerCirRerank.inference` (:373-397): sim[b, n] = max_j <text_feature_b, target_feats[n, j]>."""
+    return similarity(text_feature(sd, cfg, input_ids, attention_mask), target_feats)
+
+
 def qformer_text_only(sd: SD, cfg, prompt_embeds: Tensor, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
     """`BertModel.forward(..., no_img=True)` (Qformer.py:88-104, used by align_prompt.py:173-179): the embedding rows are
     [text[0] ([CLS]) ; the 32 prompt rows ; text[1:]], EVERY row gets its absolute position (0..63), one LayerNorm; no

@@ -12,6 +12,7 @@ from pathlib import Path
 # SPRC_LIB_PATH: an A/B build of the same library (tools/build_variant.sh); never a different implementation
 LIB_PATH = Path(os.environ.get("SPRC_LIB_PATH") or (Path(__file__).resolve().parent / "libsprc_hip.so"))
 
+SPRC_F16X3 = 4                                        # storage layout of split-precision fp16 activations ([hi | lo | hi], sprc.h)
 SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: IEEE half (compute dtype since ABI 3); FP8: OCP e4m3fn operands
 ABI_VERSION = 3
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
@@ -48,7 +49,8 @@ class AttentionArgs(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("head_dim", i32), ("dtype", i32),
                 ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64), ("out", vp), ("ldo", i64),
                 ("key_mask", vp), ("scale", f32),
-                ("k2", vp), ("ldk2", i64), ("v2", vp), ("ldv2", i64), ("Tk2", i32), ("kv_index", vp), ("kv2_index", vp)]
+                ("k2", vp), ("ldk2", i64), ("v2", vp), ("ldv2", i64), ("Tk2", i32), ("kv_index", vp), ("kv2_index", vp),
+                ("out_x3", i32)]
 
 
 class QformerEmbedArgs(C.Structure):
@@ -95,7 +97,7 @@ class QformerModel(C.Structure):
                 ("num_query", i32), ("enc_width", i32), ("embed_dim", i32), ("max_txt", i32), ("n_cross", i32),
                 ("vocab", i32), ("ln_eps", f32), ("word_emb", vp), ("pos_emb", vp), ("emb_ln_w", vp), ("emb_ln_b", vp),
                 ("query_tokens", vp), ("ckv_all", Linear), ("vision_proj", Linear), ("text_proj", Linear),
-                ("layers", C.POINTER(QfLayer))]
+                ("layers", C.POINTER(QfLayer)), ("x3", i32), ("x3_image", i32), ("x3_fuse", i32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/sprc.h declares
@@ -106,6 +108,7 @@ SIGNATURES = {
     "sprc_prof_collect": (i32, [C.POINTER(ProfEntry)]),
     "sprc_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
     "sprc_cast_f32_to_16": (i32, [vp, vp, sz, i32, vp]),
+    "sprc_cast_f32_to_x3": (i32, [vp, vp, i64, i32, vp]),
     "sprc_absmax_bf16": (i32, [vp, sz, vp, vp]),
     "sprc_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "sprc_gemm_pair": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
@@ -131,6 +134,7 @@ SIGNATURES = {
     "sprc_itm_head": (i32, [vp, i64, i32, i32, vp, vp, i32, vp, vp]),
     "sprc_qformer_fuse_train": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, sz, vp]),
     "sprc_qformer_text_only": (i32, [C.POINTER(QformerModel), vp, vp, vp, i32, vp, vp, vp, sz, vp]),
+    "sprc_qformer_text": (i32, [C.POINTER(QformerModel), vp, vp, i32, vp, vp, vp, sz, vp]),
     "sprc_contrastive_ce": (i32, [vp, i64, i32, f32, vp, vp]),
     "sprc_align_mse": (i32, [vp, i64, i32, i32, vp, i32, vp, vp]),
     "sprc_preprocess_workspace_bytes": (sz, [i32, i32, f32, i32]),

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 from argparse import ArgumentParser
 from statistics import geometric_mean, harmonic_mean, mean
 
@@ -93,7 +94,13 @@ def _preprocess(gpu: bool, device):
     return (targetpad_transform_gpu(1.25, 224, device), 2) if gpu else (targetpad_transform(1.25, 224), 2)
 
 
-def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16", index_cache=None, gpu_preprocess=False,
+def _warn_index_cache_ignored(index_cache):
+    if index_cache and _rank0():
+        print(f"warning: --index-cache {index_cache} is ignored under torchrun: every rank encodes its own gallery shard",
+              file=sys.stderr)
+
+
+def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="fp16", index_cache=None, gpu_preprocess=False,
                        vit_depth=None):
     from .data_utils import CIRRDataset
     model, txt = _load(blip_model_name, backbone, blip_model_path, dtype, vit_depth)
@@ -101,6 +108,7 @@ def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16",
     relative_val = CIRRDataset("val", "relative", preprocess)
     classic_val = CIRRDataset("val", "classic", preprocess)
     if _sharded():
+        _warn_index_cache_ignored(index_cache)
         from .dist_eval import compute_cirr_val_metrics_sharded
         r = compute_cirr_val_metrics_sharded(relative_val, classic_val, model, txt, num_workers=workers)
     else:
@@ -115,7 +123,7 @@ def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="bf16",
     return out
 
 
-def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dtype="bf16", index_cache=None, gpu_preprocess=False,
+def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dtype="fp16", index_cache=None, gpu_preprocess=False,
                       vit_depth=None):
     """FashionIQ evaluation (the reference calls this `clip_finetune_fiq`, blip_validate.py:26-98)."""
     from .data_utils import FashionIQDataset
@@ -126,6 +134,7 @@ def blip_validate_fiq(val_dress_types, blip_model_name, backbone, model_path, dt
     for d in val_dress_types:
         classic, relative = FashionIQDataset("val", [d], "classic", preprocess), FashionIQDataset("val", [d], "relative", preprocess)
         if _sharded():
+            _warn_index_cache_ignored(index_cache)
             from .dist_eval import compute_fiq_val_metrics_sharded
             r10, r50 = compute_fiq_val_metrics_sharded(relative, classic, model, txt, num_workers=workers)
         else:
@@ -153,7 +162,8 @@ def main(argv=None):
     p.add_argument("--blip-model-name", default="blip2_cir_align_prompt", type=str)
     p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
     p.add_argument("--model-path", type=str)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
+                   help="fp16 (default): the reference's GPU numerics -- fp16 ViT, Q-Former at ~fp32 product precision")
     p.add_argument("--index-cache", default=None, help="directory of gallery feature stores (sprc_amd/index.py): encode once, reuse")
     p.add_argument("--gpu-preprocess", action="store_true", help="pad / bicubic resize / crop / normalise on the GPU (bit-identical to the PIL transform)")
     p.add_argument("--vit-depth", type=int, default=None, help="truncate the ViT to N blocks (entry-point smoke tests only)")

@@ -18,7 +18,13 @@ def generate_cirr_test_submissions(file_name: str, blip_model, preprocess, txt_p
     import os
     classic = CIRRDataset("test1", "classic", preprocess)
     relative = CIRRDataset("test1", "relative", preprocess)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not rerank:       # torchrun: gallery sharded over the ranks
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and rerank:
+        # the stage-2 rerank is not sharded: every rank would encode the whole gallery, rerank every pair and write the same two
+        # files at once.  Refuse instead of doing that silently.
+        raise SystemExit("cirr_test_submission: --rerank runs on one process (launch without torchrun); the sharded path "
+                         "covers the stage-1 submission only")
+    if world > 1:                                                       # torchrun: gallery sharded over the ranks
         from .dist_eval import generate_cirr_test_dicts_sharded
         top, sub = generate_cirr_test_dicts_sharded(relative, classic, blip_model, txt_processors)
         if int(os.environ.get("RANK", "0")) != 0:
@@ -44,7 +50,7 @@ def main(argv=None):
     p.add_argument("--model-path", type=str)
     p.add_argument("--backbone", type=str, default="pretrain", help="pretrain for vit-g, pretrain_vitL for vit-l")
     p.add_argument("--rerank", type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"), default=False)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    p.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"])
     p.add_argument("--gpu-preprocess", action="store_true", help="image transform on the GPU (bit-identical to the PIL transform)")
     p.add_argument("--vit-depth", type=int, default=None, help="truncate the ViT to N blocks (entry-point smoke tests only)")
     a = p.parse_args(argv)

@@ -63,6 +63,24 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {       // RN
     const f16x2_t v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
 }
+// hi / lo halves of the split-precision layout (SPRC_F16X3): hi = fp16(x), lo = fp16(x - hi).  x is PINNED first (empty asm):
+// under hipcc's default -ffp-contract=fast the multiply that produced x is otherwise folded into each consumer separately --
+// v_cvt_pk_f16_f32 of the rounded fp32 product for the stored hi, v_fma_mixlo_f16 of the EXACT product for the hi that lo is
+// taken from -- and where the fp32 value is a tie of the fp16 grid the two disagree by one ulp (seen: 37 of 921600 outputs of a
+// GELU epilogue off by 2^-10).
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    asm("" : "+v"(x));
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+__device__ __forceinline__ void split_f16x4(float a, float b, float c, float d, f16x4& hi, f16x4& lo) {
+    _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+    split_f16(a, h0, l0); split_f16(b, h1, l1); split_f16(c, h2, l2); split_f16(d, h3, l3);
+    hi = f16x4{h0, h1, h2, h3};
+    lo = f16x4{l0, l1, l2, l3};
+}
+
 // two 16-bit operand values of the engine's compute dtype (F16: IEEE half, the reference's GPU autocast precision; else bf16)
 template <bool F16>
 __device__ __forceinline__ uint32_t pack16x2(float lo, float hi) {
@@ -90,7 +108,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 __device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 
 static inline bool is16(int dt) { return dt == SPRC_BF16 || dt == SPRC_F16; }   // 16-bit MFMA operand engines
-static inline size_t dtype_size(int dt) { return dt == SPRC_FP8 ? 1 : (dt == SPRC_BF16 || dt == SPRC_F16) ? 2 : 4; }
+static inline size_t dtype_size(int dt) { return dt == SPRC_FP8 ? 1 : (dt == SPRC_BF16 || dt == SPRC_F16 || dt == SPRC_F16X3) ? 2 : 4; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace sprc

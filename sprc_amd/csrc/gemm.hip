@@ -11,8 +11,11 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     SPRC_REQUIRE(a != nullptr, "sprc_gemm: null args");
     SPRC_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "sprc_gemm: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     SPRC_REQUIRE(a->dtype == SPRC_BF16 || a->dtype == SPRC_F16 || a->dtype == SPRC_F32 || a->dtype == SPRC_FP8, "sprc_gemm: bad dtype %d", a->dtype);
-    SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32 || a->out_dtype == SPRC_F16 || a->out_dtype == SPRC_FP8,
-                 "sprc_gemm: bad out_dtype %d", a->out_dtype);
+    SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32 || a->out_dtype == SPRC_F16 || a->out_dtype == SPRC_FP8 ||
+                     a->out_dtype == SPRC_F16X3, "sprc_gemm: bad out_dtype %d", a->out_dtype);
+    SPRC_REQUIRE(a->out_dtype != SPRC_F16X3 || (a->dtype == SPRC_F16 && !a->resid && !a->max32 && a->act != SPRC_ACT_QUICKGELU &&
+                                                a->N % 4 == 0 && a->ldc >= 3 * (int64_t)a->N),
+                 "sprc_gemm: SPRC_F16X3 output takes fp16 operands, N %% 4 == 0, ldc >= 3 N, no residual / max32 / QuickGELU");
     SPRC_REQUIRE(a->dtype != SPRC_FP8 || (a->w_scale != nullptr && a->a_scale > 0.f && !a->max32 && b == nullptr),
                  "sprc_gemm(fp8): needs w_scale, a_scale > 0; no max32 / paired launch");
     SPRC_REQUIRE(a->out_dtype != SPRC_FP8 || a->out_scale > 0.f, "sprc_gemm: SPRC_FP8 output needs out_scale > 0");
@@ -67,7 +70,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     p.debug = dbg;
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     hipStream_t st = (hipStream_t)s;
-    const double osz = a->max32 ? 4.0 / 32.0 : (double)dtype_size(a->out_dtype);
+    const double osz = a->max32 ? 4.0 / 32.0 : a->out_dtype == SPRC_F16X3 ? 6.0 : (double)dtype_size(a->out_dtype);
     const double np = b != nullptr ? 2.0 : 1.0;
     ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * a->K,
                    np * (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))));

@@ -76,6 +76,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 struct fp8_t { uint8_t bits; };        // OCP e4m3fn (gfx950), operand / output tag type
+struct f16x3_t { uint16_t bits; };     // OUTPUT tag: the split-precision layout SPRC_F16X3 ([hi | lo | hi], see sprc.h)
 
 // saturating fp32 -> 2 x e4m3fn (v_cvt_pk_fp8_f32: RNE; inputs clamped to +-448 first, the format has no infinity)
 __device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, bool hi) {
@@ -84,10 +85,17 @@ __device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, b
     return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
 }
 // 4 consecutive outputs of one row: 16 B (fp32) or 8 B (bf16 / fp16)
+// n_split: logical row width N (SPRC_F16X3 outputs only: the lo / second-hi copies sit N and 2N elements further)
 template <typename OutT>
-__device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v) {
+__device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v, int n_split = 0) {
     if constexpr (std::is_same<OutT, float>::value) {
         *reinterpret_cast<f32x4*>(dst) = v;
+    } else if constexpr (std::is_same<OutT, f16x3_t>::value) {
+        f16x4 hi, lo;
+        split_f16x4(v[0], v[1], v[2], v[3], hi, lo);
+        *reinterpret_cast<f16x4*>(dst) = hi;
+        *reinterpret_cast<f16x4*>(dst + n_split) = lo;
+        *reinterpret_cast<f16x4*>(dst + 2 * n_split) = hi;
     } else if constexpr (std::is_same<OutT, f16_t>::value) {
         typedef __attribute__((ext_vector_type(4))) _Float16 half4;
         *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -101,9 +109,14 @@ __device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v) {
 
 // one output element (the ragged-N scalar path)
 template <typename OutT>
-__device__ __forceinline__ void store_out1(OutT* dst, float v) {
+__device__ __forceinline__ void store_out1(OutT* dst, float v, int n_split = 0) {
     if constexpr (std::is_same<OutT, fp8_t>::value) dst->bits = (uint8_t)(pack_fp8x2(v, 0.f, 0u, false) & 0xffu);
-    else *dst = (OutT)v;
+    else if constexpr (std::is_same<OutT, f16x3_t>::value) {
+        _Float16 hi, lo;
+        split_f16(v, hi, lo);
+        _Float16* d = reinterpret_cast<_Float16*>(dst);
+        d[0] = hi; d[n_split] = lo; d[2 * n_split] = hi;
+    } else *dst = (OutT)v;
 }
 
 template <typename T> struct Frag;
@@ -382,7 +395,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         const int row = block_row(mi, it);
                         if (!(row < p.M && col_ok)) continue;
                         const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, row);
-                        store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v);
+                        store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v, p.N);
                     }
                     if constexpr (RES) {
                         if (mi + 2 < TM) load_resid(mi + 2, rv[mi & 1]);
@@ -431,7 +444,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         if constexpr (ACT == SPRC_ACT_QUICKGELU) v = quick_gelu(v);
                         if (rrow != nullptr) v += rrow[col];
                         if constexpr (std::is_same<OutT, fp8_t>::value) v *= p.out_scale;
-                        store_out1<OutT>(crow + col, v);
+                        store_out1<OutT>(crow + col, v, p.N);
                     }
             }
         }
@@ -614,7 +627,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
         if (resid != nullptr) v[e] += resid[(int64_t)row * ldr + col + e];
         if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= out_scale;
-        store_out1<OutT>(C + (int64_t)row * ldc + col + e, v[e]);
+        store_out1<OutT>(C + (int64_t)row * ldc + col + e, v[e], N);
     }
 }
 
@@ -1150,6 +1163,10 @@ static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st
     // 16-bit output type of this operand type: fp16 operands write fp16, everything else bf16
     constexpr bool H = std::is_same<T, f16_t>::value;
     typedef typename std::conditional<H, f16_t, bf16_t>::type O16;
+    if constexpr (H) {                                  // split-precision output of the fp16 engine's Q-Former (validated by the caller)
+        if (a->out_dtype == SPRC_F16X3)
+            return a->act == SPRC_ACT_GELU ? launch<T, f16x3_t, SPRC_ACT_GELU, false>(p, st) : launch<T, f16x3_t, SPRC_ACT_NONE, false>(p, st);
+    }
     if (a->out_dtype != SPRC_F32 && a->out_dtype != (H ? SPRC_F16 : SPRC_BF16)) {
         set_error("sprc_gemm: out_dtype %d does not go with operand dtype %d", a->out_dtype, a->dtype);
         return SPRC_EUNSUPPORTED;

@@ -28,13 +28,13 @@ struct Fp8Scales { const float* w_scale; float a_scale, out_scale; };
 static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
                 void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0,
                 sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0,
-                const Fp8Scales* q = nullptr) {
+                const Fp8Scales* q = nullptr, int64_t ldw = 0) {
     sprc_gemm_args g;
     memset(&g, 0, sizeof(g));
     if (q != nullptr) { g.w_scale = q->w_scale; g.a_scale = q->a_scale; g.out_scale = q->out_scale; }
     g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
     g.A = A; g.lda = lda; g.amap = amap;
-    g.W = w.w; g.ldw = K; g.bias = w.b;
+    g.W = w.w; g.ldw = ldw > 0 ? ldw : K; g.bias = w.b;
     g.resid = resid; g.ldr = ldr;
     g.C = C; g.ldc = ldc; g.cmap = cmap;
     g.scratch = scratch; g.scratch_bytes = scratch_bytes;
@@ -44,13 +44,13 @@ static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const v
 // two products of identical shape in one launch (sprc_gemm_pair): w0 on the rows amap0 -> cmap0, w1 on amap1 -> cmap1
 static int gemm2(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w0,
                  const sprc_linear& w1, void* C, int64_t ldc, int act, const float* resid, int64_t ldr, sprc_rowmap amap0,
-                 sprc_rowmap amap1, sprc_rowmap cmap0, sprc_rowmap cmap1) {
+                 sprc_rowmap amap1, sprc_rowmap cmap0, sprc_rowmap cmap1, int64_t ldw = 0) {
     sprc_gemm_args g[2];
     memset(g, 0, sizeof(g));
     for (int i = 0; i < 2; ++i) {
         g[i].M = M; g[i].N = N; g[i].K = K; g[i].dtype = dt; g[i].out_dtype = out_dt; g[i].act = act;
         g[i].A = A; g[i].lda = lda; g[i].amap = i ? amap1 : amap0;
-        g[i].W = (i ? w1 : w0).w; g[i].ldw = K; g[i].bias = (i ? w1 : w0).b;
+        g[i].W = (i ? w1 : w0).w; g[i].ldw = ldw > 0 ? ldw : K; g[i].bias = (i ? w1 : w0).b;
         g[i].resid = resid; g[i].ldr = ldr;
         g[i].C = C; g[i].ldc = ldc; g[i].cmap = i ? cmap1 : cmap0;
     }
@@ -61,13 +61,14 @@ static int gemm2(hipStream_t st, int dt, int out_dt, int M, int N, int K, const 
 static int lnorm(hipStream_t st, int dt, int M, int D, const float* x, const float* gam, const float* bet, float eps,
                  float* y32, void* y16, sprc_rowmap map = ID_MAP, const void* add16 = nullptr, float* sum32 = nullptr,
                  float y16_scale = 0.f) {
+    const int64_t ld16 = dt == SPRC_F16X3 ? 3 * (int64_t)D : D;
     sprc_layernorm_args a;
     memset(&a, 0, sizeof(a));
     a.M = M; a.D = D; a.out_dtype = dt;
     a.x = x; a.ldx = D; a.xmap = map;
     a.gamma = gam; a.beta = bet; a.eps = eps;
     a.y32 = y32; a.ld32 = D; a.ymap = map;
-    a.y16 = y16; a.ld16 = D;
+    a.y16 = y16; a.ld16 = ld16;
     a.add16 = add16; a.ld_add = D;
     a.sum32 = sum32; a.ld_sum = D;
     a.y16_scale = y16_scale;
@@ -84,9 +85,10 @@ struct KvSrc {
 
 static int attn(hipStream_t st, int dt, int B, int H, int Tq, int Tk, int dh, const void* q, int64_t ldq, const void* k,
                 int64_t ldk, const void* v, int64_t ldv, void* out, int64_t ldo, const float* mask, float scale,
-                const KvSrc* two = nullptr, size_t seg2_off = 0) {
+                const KvSrc* two = nullptr, size_t seg2_off = 0, bool out_x3 = false) {
     sprc_attention_args a;
     memset(&a, 0, sizeof(a));
+    a.out_x3 = out_x3 ? 1 : 0;
     a.B = B; a.H = H; a.Tq = Tq; a.Tk = Tk; a.head_dim = dh; a.dtype = dt;
     a.q = q; a.ldq = ldq; a.k = k; a.ldk = ldk; a.v = v; a.ldv = ldv; a.out = out; a.ldo = ldo;
     a.key_mask = mask; a.scale = scale;
@@ -144,27 +146,47 @@ static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& 
     const size_t es = dtype_size(m->dtype);
     const size_t S = (size_t)m->num_query + m->max_txt, R = (size_t)B * S, Hd = m->hidden;
     const size_t E = (size_t)B * enc_tokens;
-    q.enc = (with_kv && is16(m->dtype)) ? b.take(E * m->enc_width * es) : nullptr;
+    const size_t kx = m->x3 ? 3 : 1;               // split-precision Q-Former: GEMM input activations are [hi | lo | hi]
+    q.enc = (with_kv && is16(m->dtype)) ? b.take(E * m->enc_width * es * ((m->x3 & SPRC_X3_CKV) ? 3 : 1)) : nullptr;
     q.kv = with_kv ? b.take(E * (size_t)m->n_cross * 2 * Hd * es) : nullptr;
-    q.h32 = (float*)b.take(R * Hd * 4); q.h16 = b.take(R * Hd * es);
-    q.a32 = (float*)b.take(R * Hd * 4); q.a16 = b.take(R * Hd * es);
-    q.g32 = (float*)b.take(R * Hd * 4); q.g16 = b.take(R * Hd * es);
+    q.h32 = (float*)b.take(R * Hd * 4); q.h16 = b.take(R * Hd * es * kx);
+    q.a32 = (float*)b.take(R * Hd * 4); q.a16 = b.take(R * Hd * es * kx);
+    q.g32 = (float*)b.take(R * Hd * 4); q.g16 = b.take(R * Hd * es * kx);
     q.t32 = (float*)b.take(R * Hd * 4);
     q.qkv = b.take(R * 3 * Hd * es);
-    q.ctx = b.take(R * Hd * es);
+    q.ctx = b.take(R * Hd * es * kx);
     q.cq = b.take(R * Hd * es);
-    q.ffn = b.take(R * (size_t)m->ffn * es);
+    q.ffn = b.take(R * (size_t)m->ffn * es * kx);
     q.proj = (float*)b.take(R * (size_t)m->embed_dim * 4);
     q.mask = (float*)b.take(R * 4);
     return b.off;
 }
 
+// which activation buffers of a call with layer-kind mask `cm` are kept in the split layout: a buffer is split when one of the
+// layers that read it reduces over three segments
+struct X3Layouts { bool ln, ctx, ffn; };
+static X3Layouts x3_layouts(int cm) {
+    return X3Layouts{(cm & (SPRC_X3_QKV | SPRC_X3_CROSS_Q | SPRC_X3_FFN_IN | SPRC_X3_HEADS)) != 0,
+                     (cm & (SPRC_X3_ATTN_OUT | SPRC_X3_CROSS_OUT)) != 0, (cm & SPRC_X3_FFN_OUT) != 0};
+}
+
 // one Q-Former encoder stack over x32/x16 [B, S, hidden]; cross-attention + query FFN on rows [:Lq] when
 // `kv` is given (Qformer.py:434-468), text FFN on rows [Lq:]; text FFN on all rows otherwise (:469-475).
+// Split-precision (fp16 engine): `cm` is the CALL's mask over layer kinds (SPRC_X3_*, a subset of the packed mask m->x3).
+// A layer whose kind is in cm reduces over all three segments of its input -- kept in the SPRC_F16X3 layout [hi | lo | hi], leading
+// dimension 3 x width -- against its [W_hi | W_hi | W_lo] weights (K' = 3 K on the SAME fp16 GEMM kernels: products to ~2^-21); the
+// others reduce over the hi segment only (a packed weight matrix is then read through its leading dimension 3 K).  The three groups
+// of activation buffers (LayerNorm copies, attention outputs, FFN hidden) are split only when one of their consumers is in cm
+// (x3_layouts).  q / k / v and the attention probabilities stay plain fp16.
 static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int B, int S, const KvSrc* kvs,
-                    const float* mask, float* x32, void* x16) {
+                    const float* mask, float* x32, void* x16, int cm) {
     const bool with_enc = kvs != nullptr;
     const int dt = m->dtype, Hd = m->hidden, H = m->heads, dh = m->head_dim, F = m->ffn, Lq = m->num_query;
+    const X3Layouts lay = x3_layouts(cm);
+    const int adt = lay.ln ? SPRC_F16X3 : dt, fdt = lay.ffn ? SPRC_F16X3 : dt;      // dtype of the LayerNorm copies / the FFN hidden
+    const int KH = lay.ln ? 3 * Hd : Hd, KC = lay.ctx ? 3 * Hd : Hd, KF = lay.ffn ? 3 * F : F;   // their leading dimensions (ctx: KC)
+    auto kdim = [&](int kind, int width) { return (cm & kind) ? 3 * width : width; };          // reduction length of a layer
+    auto wld = [&](int kind, int width) { return (int64_t)((m->x3 & kind) ? 3 * width : width); };   // its weights' leading dimension
     const int R = B * S;
     const float sc = 1.0f / sqrtf((float)dh);                                   // Qformer.py:250
     const size_t es = dtype_size(dt);
@@ -173,85 +195,72 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
     // SPRC_FUSE_ADD=1: the post-LN residual adds (Qformer.py:294,380) ride on the LayerNorm kernels (sprc_layernorm add16),
     // the branch GEMMs write fp16 instead of running an fp32 + residual epilogue.  Off by default (see fuse_add_enabled).
     const bool fuse_add = dt == SPRC_BF16 && fuse_add_enabled(2);
+    // y = act(in . W^T + b) of layer kind `kind` over `width` input columns, into a compute-dtype (or x3) buffer
+    auto lin = [&](int kind, int rows, int N, int width, const void* in, int64_t lda, const sprc_linear& w, int odt, void* out,
+                   int64_t ldc, int act, sprc_rowmap amap, sprc_rowmap cmap) -> int {
+        return gemm(st, dt, odt, rows, N, kdim(kind, width), in, lda, w, out, ldc, act, nullptr, 0, amap, cmap, nullptr, 0, nullptr,
+                    wld(kind, width));
+    };
+    // a = LN(dense(in) + res): branch GEMM of layer kind `kind` over `width` input columns, post-LN into (o32, o16)
+    auto branch = [&](int kind, int rows, int width, int64_t lda, const void* in, const sprc_linear& w, const float* res,
+                      const float* lw, const float* lb, float* o32, void* o16, sprc_rowmap amap, sprc_rowmap cmap) -> int {
+        if (fuse_add) {         // the branch output goes out as fp16 into a16 (dead here) and is added by the LN
+            RUN(gemm(st, dt, SPRC_F16, rows, Hd, width, in, lda, w, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, amap, cmap));
+            return lnorm(st, dt, rows, Hd, res, lw, lb, m->ln_eps, o32, o16, cmap, q.a16);
+        }
+        RUN(gemm(st, dt, SPRC_F32, rows, Hd, kdim(kind, width), in, lda, w, q.t32, Hd, SPRC_ACT_NONE, res, Hd, amap, cmap, nullptr, 0,
+                 nullptr, wld(kind, width)));
+        return lnorm(st, adt, rows, Hd, q.t32, lw, lb, m->ln_eps, o32, o16, cmap);
+    };
     for (int l = 0; l < m->n_layers; ++l) {
         const sprc_qf_layer& L = m->layers[l];
         // self-attention over all S rows
-        RUN(gemm(st, dt, dt, R, 3 * Hd, Hd, x16, Hd, L.qkv, q.qkv, 3 * Hd));
+        RUN(lin(SPRC_X3_QKV, R, 3 * Hd, Hd, x16, KH, L.qkv, dt, q.qkv, 3 * Hd, SPRC_ACT_NONE, ID_MAP, ID_MAP));
         RUN(attn(st, dt, B, H, S, S, dh, q.qkv, 3 * Hd, (char*)q.qkv + Hd * es, 3 * Hd, (char*)q.qkv + 2 * Hd * es, 3 * Hd,
-                 q.ctx, Hd, mask, sc));
-        if (fuse_add) {         // a = LN(dense(ctx) + x): the branch output goes out as fp16 into a16 (dead here) and is added by the LN
-            RUN(gemm(st, dt, SPRC_F16, R, Hd, Hd, q.ctx, Hd, L.attn_out, q.a16, Hd));
-            RUN(lnorm(st, dt, R, Hd, x32, L.attn_ln_w, L.attn_ln_b, m->ln_eps, q.a32, q.a16, ID_MAP, q.a16));
-        } else {
-            RUN(gemm(st, dt, SPRC_F32, R, Hd, Hd, q.ctx, Hd, L.attn_out, q.t32, Hd, SPRC_ACT_NONE, x32, Hd));
-            RUN(lnorm(st, dt, R, Hd, q.t32, L.attn_ln_w, L.attn_ln_b, m->ln_eps, q.a32, q.a16));
-        }
+                 q.ctx, KC, mask, sc, nullptr, 0, lay.ctx));
+        RUN(branch(SPRC_X3_ATTN_OUT, R, Hd, KC, q.ctx, L.attn_out, x32, L.attn_ln_w, L.attn_ln_b, q.a32, q.a16, ID_MAP, ID_MAP));
         if (with_enc) {
             const sprc_rowmap rq = split ? qmap : ID_MAP;
             const int Rq = B * Lq;
             if (L.has_cross) {
-                RUN(gemm(st, dt, dt, Rq, Hd, Hd, q.a16, Hd, L.cq, q.cq, Hd, SPRC_ACT_NONE, nullptr, 0, rq));
+                RUN(lin(SPRC_X3_CROSS_Q, Rq, Hd, Hd, q.a16, KH, L.cq, dt, q.cq, Hd, SPRC_ACT_NONE, rq, ID_MAP));
                 const size_t off = (size_t)L.cross_index * 2 * Hd * es;          // this layer's K|V block inside a token row
                 const char* kp = (const char*)kvs->a + off;
                 const bool plain = kvs->b == nullptr && kvs->ia == nullptr;
-                RUN(attn(st, dt, B, H, Lq, kvs->Ta, dh, q.cq, Hd, kp, kvs->ld, kp + Hd * es, kvs->ld, q.ctx, Hd, nullptr, sc,
-                         plain ? nullptr : kvs, off));
-                if (fuse_add) {
-                    RUN(gemm(st, dt, SPRC_F16, Rq, Hd, Hd, q.ctx, Hd, L.cross_out, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, ID_MAP, rq));
-                    RUN(lnorm(st, dt, Rq, Hd, q.a32, L.cross_ln_w, L.cross_ln_b, m->ln_eps, q.a32, q.a16, rq, q.a16));
-                } else {
-                    RUN(gemm(st, dt, SPRC_F32, Rq, Hd, Hd, q.ctx, Hd, L.cross_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, rq));
-                    RUN(lnorm(st, dt, Rq, Hd, q.t32, L.cross_ln_w, L.cross_ln_b, m->ln_eps, q.a32, q.a16, rq));
-                }
+                RUN(attn(st, dt, B, H, Lq, kvs->Ta, dh, q.cq, Hd, kp, kvs->ld, kp + Hd * es, kvs->ld, q.ctx, KC, nullptr, sc,
+                         plain ? nullptr : kvs, off, lay.ctx));
+                RUN(branch(SPRC_X3_CROSS_OUT, Rq, Hd, KC, q.ctx, L.cross_out, q.a32, L.cross_ln_w, L.cross_ln_b, q.a32, q.a16, ID_MAP, rq));
             }
             if (split && S - Lq == Lq) {
                 // query rows and text rows of every sample go through different FFN weights (Qformer.py:455-475): the two
                 // products have the same shape, so each pair is ONE launch (sprc_gemm_pair) -- 360 + 360 tiles instead of two
                 // 1.4-round grids for the up projection, 90 + 90 instead of two third-empty grids for the down projection.
                 // The hidden activations keep the rows' natural positions in q.ffn [R, F].
-                RUN(gemm2(st, dt, dt, Rq, F, Hd, q.a16, Hd, L.ffn_q_in, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, qmap, tmap,
-                          qmap, tmap));
+                RUN(gemm2(st, dt, fdt, Rq, F, kdim(SPRC_X3_FFN_IN, Hd), q.a16, KH, L.ffn_q_in, L.ffn_t_in, q.ffn, KF, SPRC_ACT_GELU, nullptr, 0,
+                          qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_IN, Hd)));
                 if (fuse_add) {
                     RUN(gemm2(st, dt, SPRC_F16, Rq, Hd, F, q.ffn, F, L.ffn_q_out, L.ffn_t_out, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, qmap,
                               tmap, qmap, tmap));
                     RUN(lnorm(st, dt, Rq, Hd, q.a32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, qmap, q.a16));
                     RUN(lnorm(st, dt, Rq, Hd, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap, q.a16));
                 } else {
-                    RUN(gemm2(st, dt, SPRC_F32, Rq, Hd, F, q.ffn, F, L.ffn_q_out, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, qmap,
-                              tmap, qmap, tmap));
-                    RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, qmap));
-                    RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
+                    RUN(gemm2(st, dt, SPRC_F32, Rq, Hd, kdim(SPRC_X3_FFN_OUT, F), q.ffn, KF, L.ffn_q_out, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE,
+                              q.a32, Hd, qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_OUT, F)));
+                    RUN(lnorm(st, adt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, qmap));
+                    RUN(lnorm(st, adt, Rq, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
                 }
             } else {
-                RUN(gemm(st, dt, dt, Rq, F, Hd, q.a16, Hd, L.ffn_q_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, rq));
-                if (fuse_add) {
-                    RUN(gemm(st, dt, SPRC_F16, Rq, Hd, F, q.ffn, F, L.ffn_q_out, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, ID_MAP, rq));
-                    RUN(lnorm(st, dt, Rq, Hd, q.a32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, rq, q.a16));
-                } else {
-                    RUN(gemm(st, dt, SPRC_F32, Rq, Hd, F, q.ffn, F, L.ffn_q_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, rq));
-                    RUN(lnorm(st, dt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, rq));
-                }
+                RUN(lin(SPRC_X3_FFN_IN, Rq, F, Hd, q.a16, KH, L.ffn_q_in, fdt, q.ffn, KF, SPRC_ACT_GELU, rq, ID_MAP));
+                RUN(branch(SPRC_X3_FFN_OUT, Rq, F, KF, q.ffn, L.ffn_q_out, q.a32, L.ffn_q_ln_w, L.ffn_q_ln_b, x32, x16, ID_MAP, rq));
                 if (split) {
                     const int Rt = B * (S - Lq);
-                    RUN(gemm(st, dt, dt, Rt, F, Hd, q.a16, Hd, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU, nullptr, 0, tmap));
-                    if (fuse_add) {
-                        RUN(gemm(st, dt, SPRC_F16, Rt, Hd, F, q.ffn, F, L.ffn_t_out, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, ID_MAP, tmap));
-                        RUN(lnorm(st, dt, Rt, Hd, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap, q.a16));
-                    } else {
-                        RUN(gemm(st, dt, SPRC_F32, Rt, Hd, F, q.ffn, F, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd, ID_MAP, tmap));
-                        RUN(lnorm(st, dt, Rt, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
-                    }
+                    RUN(lin(SPRC_X3_FFN_IN, Rt, F, Hd, q.a16, KH, L.ffn_t_in, fdt, q.ffn, KF, SPRC_ACT_GELU, tmap, ID_MAP));
+                    RUN(branch(SPRC_X3_FFN_OUT, Rt, F, KF, q.ffn, L.ffn_t_out, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, x32, x16, ID_MAP, tmap));
                 }
             }
         } else {
-            RUN(gemm(st, dt, dt, R, F, Hd, q.a16, Hd, L.ffn_t_in, q.ffn, F, SPRC_ACT_GELU));
-            if (fuse_add) {
-                RUN(gemm(st, dt, SPRC_F16, R, Hd, F, q.ffn, F, L.ffn_t_out, q.a16, Hd));
-                RUN(lnorm(st, dt, R, Hd, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, ID_MAP, q.a16));
-            } else {
-                RUN(gemm(st, dt, SPRC_F32, R, Hd, F, q.ffn, F, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE, q.a32, Hd));
-                RUN(lnorm(st, dt, R, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16));
-            }
+            RUN(lin(SPRC_X3_FFN_IN, R, F, Hd, q.a16, KH, L.ffn_t_in, fdt, q.ffn, KF, SPRC_ACT_GELU, ID_MAP, ID_MAP));
+            RUN(branch(SPRC_X3_FFN_OUT, R, F, KF, q.ffn, L.ffn_t_out, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, x32, x16, ID_MAP, ID_MAP));
         }
     }
     return SPRC_OK;
@@ -259,20 +268,35 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
 
 // K|V projections of the image tokens for every cross-attention layer in ONE GEMM (Qformer.py:191-193)
 static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, void* enc16, void* kv_out, const float* enc32, int B,
-                        int enc_tokens) {
+                        int enc_tokens, int cm) {
     const int E = B * enc_tokens;
     const void* enc = enc32;
-    if (is16(m->dtype)) {
+    const bool kv3 = (cm & SPRC_X3_CKV) != 0;
+    if (kv3) {
+        RUN(sprc_cast_f32_to_x3(enc32, enc16, E, m->enc_width, st));
+        enc = enc16;
+    } else if (is16(m->dtype)) {
         RUN(sprc_cast_f32_to_16(enc32, enc16, (size_t)E * m->enc_width, m->dtype, st));
         enc = enc16;
     }
-    const int Nkv = m->n_cross * 2 * m->hidden;
-    return gemm(st, m->dtype, m->dtype, E, Nkv, m->enc_width, enc, m->enc_width, m->ckv_all, kv_out, Nkv);
+    const int Nkv = m->n_cross * 2 * m->hidden, Kx = m->enc_width * (kv3 ? 3 : 1);
+    return gemm(st, m->dtype, m->dtype, E, Nkv, Kx, enc, Kx, m->ckv_all, kv_out, Nkv, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP, nullptr, 0,
+                nullptr, (int64_t)m->enc_width * ((m->x3 & SPRC_X3_CKV) ? 3 : 1));
+}
+
+// out[rows, embed_dim] (fp32) = proj(hidden rows `amap` of x16): the ITC heads (align_prompt.py:348,385)
+static int head(const sprc_qformer_model* m, hipStream_t st, int cm, int rows, const void* x16, const sprc_linear& w, float* out,
+                sprc_rowmap amap) {
+    const int Hd = m->hidden;
+    return gemm(st, m->dtype, SPRC_F32, rows, m->embed_dim, (cm & SPRC_X3_HEADS) ? 3 * Hd : Hd, x16, x3_layouts(cm).ln ? 3 * Hd : Hd, w, out, m->embed_dim,
+                SPRC_ACT_NONE, nullptr, 0, amap, ID_MAP, nullptr, 0, nullptr, (int64_t)((m->x3 & SPRC_X3_HEADS) ? 3 * Hd : Hd));
 }
 
 static int check_qf(const sprc_qformer_model* m) {
     SPRC_REQUIRE(m && m->layers, "qformer: null model");
     SPRC_REQUIRE(is16(m->dtype) || m->dtype == SPRC_F32, "qformer: bad dtype");
+    SPRC_REQUIRE(!m->x3 || m->dtype == SPRC_F16, "qformer: the split-precision mode (x3) needs dtype SPRC_F16");
+    SPRC_REQUIRE((m->x3_image & ~m->x3) == 0 && (m->x3_fuse & ~m->x3) == 0, "qformer: x3_image / x3_fuse must be subsets of the packed mask x3");
     SPRC_REQUIRE(m->hidden == m->heads * m->head_dim, "qformer: hidden != heads*head_dim");
     SPRC_REQUIRE((m->num_query & (m->num_query - 1)) == 0 && (m->max_txt & (m->max_txt - 1)) == 0,
                  "qformer: num_query and max_txt must be powers of two");
@@ -443,17 +467,18 @@ extern "C" int sprc_qformer_image(const sprc_qformer_model* m, const float* raw,
     }
     hipStream_t st = (hipStream_t)s;
     const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query;
-    RUN(qf_encode_kv(m, st, q.enc, q.kv, raw, B, T));
+    const int cm = m->x3_image;
+    RUN(qf_encode_kv(m, st, q.enc, q.kv, raw, B, T, cm));
     const KvSrc kvs{q.kv, T, nullptr, nullptr, 0, nullptr, (int64_t)m->n_cross * 2 * Hd};
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
-    e.B = B; e.Lq = Lq; e.Lt = 0; e.hidden = Hd; e.out_dtype = dt;
+    e.B = B; e.Lq = Lq; e.Lt = 0; e.hidden = Hd; e.out_dtype = x3_layouts(cm).ln ? SPRC_F16X3 : dt;
     e.query_embeds = m->query_tokens; e.q_bstride = 0;
     e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, Lq, &kvs, nullptr, q.h32, q.h16));
-    RUN(gemm(st, dt, SPRC_F32, B * Lq, m->embed_dim, Hd, q.h16, Hd, m->vision_proj, q.proj, m->embed_dim));
+    RUN(qf_stack(m, st, q, B, Lq, &kvs, nullptr, q.h32, q.h16, cm));
+    RUN(head(m, st, cm, B * Lq, q.h16, m->vision_proj, q.proj, ID_MAP));
     return sprc_l2norm_rows(q.proj, m->embed_dim, feats, feats16, m->embed_dim, B * Lq, m->embed_dim, dt, st);
 }
 
@@ -473,29 +498,30 @@ static int qformer_fuse_impl(const sprc_qformer_model* m, const float* ref_embed
     }
     hipStream_t st = (hipStream_t)s;
     const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query, Lt = m->max_txt, S = Lq + Lt;
-    RUN(qf_encode_kv(m, st, q.enc, q.kv, ref_embeds, B, enc_tokens));
+    const int cm = m->x3_fuse;
+    RUN(qf_encode_kv(m, st, q.enc, q.kv, ref_embeds, B, enc_tokens, cm));
     const KvSrc kvs{q.kv, enc_tokens, nullptr, nullptr, 0, nullptr, (int64_t)m->n_cross * 2 * Hd};
     RUN(sprc_qformer_mask(attention_mask, q.mask, B, Lq, Lt, st));
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
-    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt; e.vocab = m->vocab;
+    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = x3_layouts(cm).ln ? SPRC_F16X3 : dt; e.vocab = m->vocab;
     e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
     e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
     // pass 1: learned query tokens + text, cross-attention to the reference image (align_prompt.py:332-339)
     e.query_embeds = m->query_tokens; e.q_bstride = 0;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, &kvs, q.mask, q.h32, q.h16));
+    RUN(qf_stack(m, st, q, B, S, &kvs, q.mask, q.h32, q.h16, cm));
     if (loss_align != nullptr)                  // training: mse(mean fused query token, mean prompt token)  (align_prompt.py:192-193)
         RUN(sprc_align_mse(q.h32, (int64_t)S * Hd, Lq, Hd, prompt_tokens, B, loss_align, st));
     // pass 2: pass-1 query rows as query_embeds (re-LayerNormed by the embedding LN), no image (:341-346)
     e.query_embeds = q.h32; e.q_bstride = (int64_t)S * Hd;
     e.y32 = q.g32; e.y16 = q.g16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.g32, q.g16));
+    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.g32, q.g16, cm));
     // fusion = normalize(text_proj(pass2[:, 32, :]))  (:348-350): row Lq of every sample
     const sprc_rowmap cls_row = {1, S, Lq};
-    RUN(gemm(st, dt, SPRC_F32, B, m->embed_dim, Hd, q.g16, Hd, m->text_proj, q.proj, m->embed_dim, SPRC_ACT_NONE, nullptr, 0, cls_row));
+    RUN(head(m, st, cm, B, q.g16, m->text_proj, q.proj, cls_row));
     return sprc_l2norm_rows(q.proj, m->embed_dim, fusion, fusion16, m->embed_dim, B, m->embed_dim, dt, st);
 }
 
@@ -533,22 +559,51 @@ extern "C" int sprc_qformer_text_only(const sprc_qformer_model* m, const float* 
     RUN(sprc_qformer_mask(attention_mask, q.mask, B, Lq, Lt, st));          // cat([ones(32), text mask]) as the reference passes it (:174-176)
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
-    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt; e.vocab = m->vocab; e.no_img = 1;
+    const int cm = m->x3_fuse;
+    e.B = B; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = x3_layouts(cm).ln ? SPRC_F16X3 : dt; e.vocab = m->vocab; e.no_img = 1;
     e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
     e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
     e.query_embeds = prompt_tokens; e.q_bstride = 0;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.h32, q.h16));
+    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.h32, q.h16, cm));
     const sprc_rowmap row0 = {1, S, 0};                                      // last_hidden_state[:, 0, :]  (:177-179)
-    RUN(gemm(st, dt, SPRC_F32, B, m->embed_dim, Hd, q.h16, Hd, m->text_proj, q.proj, m->embed_dim, SPRC_ACT_NONE, nullptr, 0, row0));
+    RUN(head(m, st, cm, B, q.h16, m->text_proj, q.proj, row0));
+    return sprc_l2norm_rows(q.proj, m->embed_dim, feat, feat16, m->embed_dim, B, m->embed_dim, dt, st);
+}
+
+extern "C" int sprc_qformer_text(const sprc_qformer_model* m, const int64_t* input_ids, const int64_t* attention_mask, int32_t B,
+                                 float* feat, void* feat16, void* ws, size_t ws_bytes, sprc_stream s) {
+    RUN(check_qf(m));
+    SPRC_REQUIRE(input_ids && attention_mask && feat && ws && B > 0, "sprc_qformer_text: bad arguments");
+    SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_qformer_text: workspace must be 256-byte aligned");
+    Bump b(ws, ws_bytes);
+    QfBufs q;
+    qf_plan(m, B, 0, b, q, false);
+    if (!b.ok) {
+        set_error("sprc_qformer_text: workspace too small (%zu bytes given)", ws_bytes);
+        return SPRC_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)s;
+    const int dt = m->dtype, Hd = m->hidden, Lt = m->max_txt, cm = m->x3_fuse;
+    RUN(sprc_qformer_mask(attention_mask, q.mask, B, 0, Lt, st));              // (1 - mask) * -10000 over the Lt text keys (Qformer.py:806-807)
+    sprc_qformer_embed_args e;
+    memset(&e, 0, sizeof(e));
+    e.B = B; e.Lq = 0; e.Lt = Lt; e.hidden = Hd; e.out_dtype = x3_layouts(cm).ln ? SPRC_F16X3 : dt; e.vocab = m->vocab;
+    e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
+    e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
+    e.y32 = q.h32; e.y16 = q.h16;
+    RUN(sprc_qformer_embed(&e, st));
+    RUN(qf_stack(m, st, q, B, Lt, nullptr, q.mask, q.h32, q.h16, cm));
+    const sprc_rowmap row0 = {1, Lt, 0};                                     // last_hidden_state[:, 0, :]  (rerank.py:388-390)
+    RUN(head(m, st, cm, B, q.h16, m->text_proj, q.proj, row0));
     return sprc_l2norm_rows(q.proj, m->embed_dim, feat, feat16, m->embed_dim, B, m->embed_dim, dt, st);
 }
 
 // ---- stage-2 rerank: blip2_qformer_cir_rerank.py:399-445 ------------------------------------------
 extern "C" size_t sprc_qformer_kv_workspace_bytes(const sprc_qformer_model* m, int32_t B, int32_t tokens) {
     if (!m || B <= 0 || tokens <= 0) return 0;
-    return (is16(m->dtype) ? (size_t)B * tokens * m->enc_width * 2 : 0) + 512;
+    return (is16(m->dtype) ? (size_t)B * tokens * m->enc_width * 2 * ((m->x3 & SPRC_X3_CKV) ? 3 : 1) : 0) + 512;
 }
 
 extern "C" int sprc_qformer_encode_kv(const sprc_qformer_model* m, const float* raw, int32_t B, int32_t tokens, void* kv,
@@ -558,7 +613,7 @@ extern "C" int sprc_qformer_encode_kv(const sprc_qformer_model* m, const float* 
     SPRC_REQUIRE(!is16(m->dtype) || (ws && ((uintptr_t)ws % 256) == 0 && ws_bytes >= sprc_qformer_kv_workspace_bytes(m, B, tokens) - 512),
                  "sprc_qformer_encode_kv: workspace too small or misaligned");
     SPRC_REQUIRE(((uintptr_t)kv % 16) == 0, "sprc_qformer_encode_kv: kv must be 16-byte aligned");
-    return qf_encode_kv(m, (hipStream_t)s, ws, kv, raw, B, tokens);
+    return qf_encode_kv(m, (hipStream_t)s, ws, kv, raw, B, tokens, m->x3_fuse);
 }
 
 extern "C" size_t sprc_qformer_itm_workspace_bytes(const sprc_qformer_model* m, int32_t P) {
@@ -588,7 +643,8 @@ extern "C" int sprc_qformer_itm(const sprc_qformer_model* m, const float* itm_w,
     RUN(sprc_qformer_mask(attention_mask, q.mask, P, Lq, Lt, st));
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
-    e.B = P; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = dt; e.vocab = m->vocab;
+    const int cm = m->x3_fuse;
+    e.B = P; e.Lq = Lq; e.Lt = Lt; e.hidden = Hd; e.out_dtype = x3_layouts(cm).ln ? SPRC_F16X3 : dt; e.vocab = m->vocab;
     e.input_ids = input_ids; e.word_emb = m->word_emb; e.pos_emb = m->pos_emb;
     e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
     e.query_embeds = m->query_tokens; e.q_bstride = 0;
@@ -596,7 +652,7 @@ extern "C" int sprc_qformer_itm(const sprc_qformer_model* m, const float* itm_w,
     RUN(sprc_qformer_embed(&e, st));
     // one Q-Former pass in call shape (ii) over cat(reference, candidate) tokens (:430-437)
     const KvSrc kvs{kv_a, tokens_a, index_a, kv_b, tokens_b, index_b, (int64_t)m->n_cross * 2 * Hd};
-    RUN(qf_stack(m, st, q, P, S, &kvs, q.mask, q.h32, q.h16));
+    RUN(qf_stack(m, st, q, P, S, &kvs, q.mask, q.h32, q.h16, cm));
     // itm_head on the query rows, mean over them, softmax, P(match)  (:439-445)
     return sprc_itm_head(q.h32, (int64_t)S * Hd, Lq, Hd, itm_w, itm_b, P, prob, st);
 }

@@ -51,7 +51,7 @@ __device__ __forceinline__ void layernorm_regs(RowRegs& r, int nch, int D, int l
     }
 }
 
-// KIND: the operand copy's type -- 0 fp32, 1 bf16, 2 fp16 (SPRC_F32 / SPRC_BF16 / SPRC_F16)
+// KIND: the operand copy's type -- 0 fp32, 1 bf16, 2 fp16, 3 split fp16 [hi | lo | hi] (SPRC_F32 / _BF16 / _F16 / _F16X3)
 template <int KIND>
 __device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y16, int nch, int lane) {
 #pragma unroll
@@ -60,7 +60,13 @@ __device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y1
         if (i < nch) {
             if (y32) reinterpret_cast<float4*>(y32)[i] = r.v[c];
             if (y16) {
-                if constexpr (KIND != 0) {
+                if constexpr (KIND == 3) {               // row width D = 4 nch: lo and the second hi copy sit D and 2 D elements further
+                    typedef f16x4 half4;
+                    half4 hi, lo;
+                    split_f16x4(r.v[c].x, r.v[c].y, r.v[c].z, r.v[c].w, hi, lo);
+                    half4* d = reinterpret_cast<half4*>(y16);
+                    d[i] = hi; d[nch + i] = lo; d[2 * nch + i] = hi;
+                } else if constexpr (KIND != 0) {
                     uint2 pk;
                     pk.x = pack16x2<KIND == 2>(r.v[c].x, r.v[c].y);
                     pk.y = pack16x2<KIND == 2>(r.v[c].z, r.v[c].w);
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc
     }
     layernorm_regs(r, nch, p.hidden, lane, p.gamma, p.beta, p.eps);
     store_row<KIND>(r, p.y32 ? p.y32 + (int64_t)row * p.hidden : nullptr,
-                    p.y16 ? (char*)p.y16 + (int64_t)row * p.hidden * (KIND ? 2 : 4) : nullptr, nch, lane);
+                    p.y16 ? (char*)p.y16 + (int64_t)row * p.hidden * (KIND == 3 ? 6 : KIND ? 2 : 4) : nullptr, nch, lane);
 }
 
 template <int KIND>
@@ -304,6 +310,31 @@ extern "C" int sprc_cast_f32_to_16(const float* src, void* dst, size_t n, int32_
     return SPRC_OK;
 }
 
+// fp32 [rows, cols] -> split fp16 [rows, 3 cols] = [hi | lo | hi]
+__global__ void cast_x3_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t rows, int cols4) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+    const int64_t total = rows * cols4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t row = e / cols4;
+        const int c = (int)(e - row * cols4);
+        const float4 v = reinterpret_cast<const float4*>(src)[e];
+        half4 hi, lo;
+        split_f16x4(v.x, v.y, v.z, v.w, hi, lo);
+        half4* d = reinterpret_cast<half4*>(dst) + row * 3 * cols4;
+        d[c] = hi; d[cols4 + c] = lo; d[2 * cols4 + c] = hi;
+    }
+}
+
+extern "C" int sprc_cast_f32_to_x3(const float* src, void* dst, int64_t rows, int32_t cols, sprc_stream s) {
+    SPRC_REQUIRE(src && dst && rows >= 0 && cols > 0 && cols % 4 == 0, "sprc_cast_f32_to_x3: bad arguments (cols %% 4 == 0)");
+    if (rows == 0) return SPRC_OK;
+    SPRC_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "sprc_cast_f32_to_x3: misaligned");
+    hipLaunchKernelGGL(cast_x3_kernel, dim3(grid_for(rows * (cols / 4), 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, src,
+                       reinterpret_cast<_Float16*>(dst), rows, cols / 4);
+    SPRC_CHECK_LAUNCH("sprc_cast_f32_to_x3");
+    return SPRC_OK;
+}
+
 extern "C" int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s) {
     return sprc_cast_f32_to_16(src, dst, n, SPRC_BF16, s);
 }
@@ -329,6 +360,10 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
         hipLaunchKernelGGL(layernorm_fp8_kernel, grid, block, 0, (hipStream_t)s, p, a->y16_scale);
     } else if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, (hipStream_t)s, p);
     else if (a->out_dtype == SPRC_F16) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, (hipStream_t)s, p);
+    else if (a->out_dtype == SPRC_F16X3) {
+        SPRC_REQUIRE(a->y16 == nullptr || (a->ld16 >= 3 * (int64_t)a->D && ((uintptr_t)a->y16 % 8) == 0), "sprc_layernorm(F16X3): ld16 >= 3 D, y16 8-byte aligned");
+        hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, (hipStream_t)s, p);
+    }
     else hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, (hipStream_t)s, p);
     SPRC_CHECK_LAUNCH("sprc_layernorm");
     return SPRC_OK;
@@ -454,8 +489,8 @@ extern "C" int sprc_itm_head(const float* h, int64_t sample_stride, int32_t Lq, 
 }
 
 extern "C" int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream s) {
-    SPRC_REQUIRE(a && a->query_embeds && a->gamma && a->beta, "sprc_qformer_embed: null pointer");
-    SPRC_REQUIRE(a->B > 0 && a->Lq > 0 && a->Lt >= 0, "sprc_qformer_embed: bad shape");
+    SPRC_REQUIRE(a && a->gamma && a->beta && (a->query_embeds || a->Lq == 0), "sprc_qformer_embed: null pointer");
+    SPRC_REQUIRE(a->B > 0 && a->Lq >= 0 && a->Lt >= 0 && a->Lq + a->Lt > 0 && (a->Lq > 0 || !a->no_img), "sprc_qformer_embed: bad shape");
     SPRC_REQUIRE(a->Lt == 0 || (a->input_ids && a->word_emb && a->pos_emb), "sprc_qformer_embed: text tables missing");
     SPRC_REQUIRE(!a->no_img || a->Lt > 0, "sprc_qformer_embed: no_img needs text");
     SPRC_REQUIRE(a->hidden % 4 == 0 && a->hidden <= 64 * 4 * MAXC, "sprc_qformer_embed: hidden=%d unsupported", a->hidden);
@@ -463,6 +498,7 @@ extern "C" int sprc_qformer_embed(const sprc_qformer_embed_args* a, sprc_stream 
     const dim3 grid((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
     if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(qformer_embed_kernel<1>, grid, block, 0, (hipStream_t)s, *a);
     else if (a->out_dtype == SPRC_F16) hipLaunchKernelGGL(qformer_embed_kernel<2>, grid, block, 0, (hipStream_t)s, *a);
+    else if (a->out_dtype == SPRC_F16X3) hipLaunchKernelGGL(qformer_embed_kernel<3>, grid, block, 0, (hipStream_t)s, *a);
     else hipLaunchKernelGGL(qformer_embed_kernel<0>, grid, block, 0, (hipStream_t)s, *a);
     SPRC_CHECK_LAUNCH("sprc_qformer_embed");
     return SPRC_OK;

@@ -64,6 +64,14 @@ class HostTargetPad:
         return (x - mean) / std
 
 
+# Image modes for which "convert to RGB, then pad / resize / crop" (what the GPU transform does) equals the reference's order
+# "pad / resize / crop in the image's own mode, convert last" (data_utils.py:49-105: TargetPad and Resize run before
+# _convert_image_to_rgb): RGB trivially, L because grey -> RGB replicates the channel and commutes with a per-channel resampler.
+# Palette ("P") and bilevel ("1") images are resized with NEAREST by PIL and padded with palette index 0; RGBA / LA are resampled
+# with premultiplied alpha; 16-bit and float modes have their own paths -- those go through the PIL transform on the host.
+GPU_EXACT_MODES = ("RGB", "L")
+
+
 def targetpad_transform(target_ratio: float, dim: int) -> Callable:
     return HostTargetPad(target_ratio, dim)
 
@@ -87,9 +95,12 @@ class GpuTargetPad:
         self.mean = (C.c_float * 3)(*CLIP_MEAN)
         self.std = (C.c_float * 3)(*CLIP_STD)
         self._ws = None
+        self._host = HostTargetPad(self.ratio, self.dim)
 
     def __call__(self, image) -> torch.Tensor:
         if not isinstance(image, (np.ndarray, torch.Tensor)):
+            if image.mode not in GPU_EXACT_MODES:                           # see GPU_EXACT_MODES: PIL's own per-mode behaviour
+                return self._host(image).to(self.device, non_blocking=True)
             image = np.asarray(image.convert("RGB"), dtype=np.uint8)       # _convert_image_to_rgb (data_utils.py:74-75)
         src = torch.from_numpy(np.array(image, dtype=np.uint8, order="C")) if isinstance(image, np.ndarray) else image.contiguous()
         if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3:
@@ -111,10 +122,22 @@ class GpuTargetPad:
 
 class DecodeRGB:
     """The host half of `GpuTargetPad`: PIL image -> uint8 RGB tensor [H, W, 3] (_convert_image_to_rgb, data_utils.py:74-75).
-    What loader WORKERS run when the pixel work is on the GPU (sprc_amd/harness.py: extract_index_blip_features)."""
+    What loader WORKERS run when the pixel work is on the GPU (sprc_amd/harness.py: extract_index_blip_features).
+    Images in a mode the GPU transform does not reproduce (GPU_EXACT_MODES) are transformed here, on the host, and come out as
+    the finished fp32 [3, dim, dim] tensor instead (the harness passes those through: `is_transformed`)."""
+
+    def __init__(self, target_ratio: float = 1.25, dim: int = 224):
+        self._host = HostTargetPad(target_ratio, dim)
 
     def __call__(self, image) -> torch.Tensor:
+        if image.mode not in GPU_EXACT_MODES:
+            return self._host(image)
         return torch.from_numpy(np.array(image.convert("RGB"), dtype=np.uint8, order="C"))
+
+
+def is_transformed(item: torch.Tensor) -> bool:
+    """True for a finished [3, dim, dim] fp32 item (host transform), False for a decoded uint8 [H, W, 3] image."""
+    return item.dtype == torch.float32
 
 
 def targetpad_transform_gpu(target_ratio: float, dim: int, device="cuda") -> Callable:

@@ -84,8 +84,14 @@ class ShardedRanker:
     """Ranks queries against a gallery sharded over the ranks of `group`."""
 
     def __init__(self, local_feats: torch.Tensor, index_base: int, sim_fn: SimFn = _hip_sim, topk_fn: TopkFn = _hip_topk,
-                 group=None):
+                 group=None, always_exchange: Optional[bool] = None):
+        """always_exchange (default: environment SPRC_DIST_ALWAYS_EXCHANGE=1): run both all_gathers and the merge even in a
+        one-rank group -- same result, and the RCCL path of a 1-GPU box is then the path an 8-GPU node takes."""
         self.feats, self.base, self.sim_fn, self.topk_fn, self.group = local_feats, int(index_base), sim_fn, topk_fn, group
+        if always_exchange is None:
+            import os
+            always_exchange = os.environ.get("SPRC_DIST_ALWAYS_EXCHANGE", "0") == "1"
+        self.always_exchange = bool(always_exchange)
 
     def rank(self, fusion_local: torch.Tensor, k: int, listed: Optional[torch.Tensor] = None,
              select: Optional[torch.Tensor] = None):
@@ -98,7 +104,8 @@ class ShardedRanker:
                 (CIRR subset members / targets): the owner of each contributes its score in the SAME all_gather as
                 the per-shard top-k; returns a third tensor listed_sim[nq,L] (-inf where -1)."""
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        fusion = _all_gather_rows(fusion_local, self.group) if world > 1 else fusion_local     # exchange 1
+        exchange = world > 1 or (self.always_exchange and dist.is_initialized())
+        fusion = _all_gather_rows(fusion_local, self.group) if exchange else fusion_local       # exchange 1
         if select is not None:
             fusion = fusion.index_select(0, select.to(fusion.device))
         nq, n_local = fusion.shape[0], self.feats.shape[0]
@@ -110,7 +117,7 @@ class ShardedRanker:
             own = (col >= 0) & (col < n_local)
             lv = torch.where(own, sim.gather(1, col.clamp(0, max(n_local - 1, 0))) if n_local else torch.zeros_like(col, dtype=sim.dtype),
                              torch.full(col.shape, float("-inf"), dtype=sim.dtype, device=sim.device))
-        if world == 1:
+        if not exchange:
             return (vals, idx) if listed is None else (vals, idx, lv)
         # exchange 2: ONE all_gather of [nq, k (score bits) + k (global index) + L (listed score bits)] int32 per rank
         parts = [vals.contiguous().view(torch.int32), idx] + ([lv.contiguous().view(torch.int32)] if lv is not None else [])

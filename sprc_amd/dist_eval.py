@@ -138,7 +138,9 @@ def encode_gallery_shard(classic_dataset, blip_model, reference_names: Optional[
     keep = None if reference_names is None else set(reference_names)
     (feats, raw_store), names_local = extract_fn(Subset(classic_dataset, range(lo, hi)), blip_model, batch_size=batch_size,
                                                  num_workers=num_workers, keep_raw=keep if keep is not None else True)
-    if world > 1:                            # a slice may have lost unreadable images: exchange the actual name lists
+    import os
+    if world > 1 or (dist.is_initialized() and os.environ.get("SPRC_DIST_ALWAYS_EXCHANGE", "0") == "1"):
+        # a slice may have lost unreadable images: exchange the actual name lists
         gathered: List[Optional[List[str]]] = [None] * world
         dist.all_gather_object(gathered, list(names_local), group=group)
     else:
@@ -205,7 +207,7 @@ def _pct(hits: np.ndarray) -> float:
 
 def _position(top_idx: np.ndarray, wanted: np.ndarray) -> np.ndarray:
     """position of wanted[q] in top_idx[q] (k where absent)."""
-    hit = top_idx == wanted[:, None]
+    hit = (top_idx == wanted[:, None]) & (top_idx >= 0)          # -1 = an unused slot of a gallery with < k rows, never a hit
     return np.where(hit.any(1), hit.argmax(1), top_idx.shape[1])
 
 
@@ -228,7 +230,9 @@ def cirr_val_metrics_from_topk(top_idx, listed_sim, ref_idx, tgt_idx, group_idx)
 
 
 def fiq_metrics_from_topk(top_idx, tgt_idx) -> Tuple[float, float]:
-    pos = _position(np.asarray(top_idx, dtype=np.int64), np.asarray(tgt_idx, dtype=np.int64))
+    tgt_idx = np.asarray(tgt_idx, dtype=np.int64)
+    assert (tgt_idx >= 0).all(), "every query needs its target in the gallery (validate_blip.py:51 asserts one label per query)"
+    pos = _position(np.asarray(top_idx, dtype=np.int64), tgt_idx)
     return _pct(pos < 10), _pct(pos < 50)                            # validate_blip.py:44-57 (reference kept)
 
 

@@ -16,6 +16,14 @@ from .config import SprcConfig
 
 _TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16, L.SPRC_F16: torch.float16, L.SPRC_FP8: torch.float8_e4m3fn}
 _SPRC_DT = {v: k for k, v in _TORCH_DT.items()}
+# layer kinds of the split-precision Q-Former (include/sprc.h: SPRC_X3_*)
+X3_QKV, X3_ATTN_OUT, X3_CROSS_Q, X3_CROSS_OUT, X3_FFN_IN, X3_FFN_OUT, X3_CKV, X3_HEADS, X3_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 255
+# Default split-precision masks of the fp16 engine: (image pass, query-side passes).  Chosen on the full-depth planted golden
+# (tools/x3_sweep.py, MI355X; max|dsim| / rms / Q-Former ms per bench step): none 1.34e-3 / 3.2e-4 / 15.1 -- everything
+# 5.1e-4 / 1.6e-4 / 30.5 -- this choice 7.6e-4 / 2.2e-4 / 20.2.  The gallery features carry 4x the error variance of the fused
+# queries at a fifth of the Q-Former's work, so the image pass splits everything but the self-attention Q|K|V product (the
+# most expensive and least sensitive kind) and the query side only the four kinds that cost next to nothing.
+X3_DEFAULT = (X3_ALL & ~X3_QKV, X3_ATTN_OUT | X3_CROSS_Q | X3_CROSS_OUT | X3_HEADS)
 FP8_MAX = 448.0                                   # largest finite e4m3fn
 
 
@@ -189,10 +197,15 @@ class Engine:
     """Packed weights + workspaces for one model on one GPU."""
 
     def __init__(self, cfg: SprcConfig, state_dict: Dict[str, torch.Tensor], device, dtype: str = "bf16",
-                 max_batch: int = 128, fp8_amax: Optional[torch.Tensor] = None, fp8_margin: float = 1.0):
+                 max_batch: int = 128, fp8_amax: Optional[torch.Tensor] = None, fp8_margin: float = 1.0,
+                 qformer_x3=None):
         """dtype "fp8": a bf16 engine whose ViT qkv / fc1 / fc2 GEMMs run on e4m3fn operands (BASELINE.json config C5).
         fp8_amax [depth, 3]: max |x| of those GEMMs' inputs from `calibrate_fp8` on representative images (static
-        per-tensor activation scales = amax * fp8_margin / 448); weights get per-output-channel scales."""
+        per-tensor activation scales = amax * fp8_margin / 448); weights get per-output-channel scales.
+        dtype "fp16": fp16 MFMA operands -- the reference's GPU numerics are a fp16-autocast ViT and an fp32 Q-Former
+        (align_prompt.py:366-368: the Q-Former runs OUTSIDE `maybe_autocast`); qformer_x3 (default: on for fp16) keeps the
+        Q-Former at ~fp32 product precision on the fp16 MFMA by splitting weights and activations into hi + lo halves
+        (SPRC_F16X3, include/sprc.h): three fp16 products per fp32 product instead of the 16x slower exact-fp32 MFMA."""
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -206,6 +219,17 @@ class Engine:
         self.dt = L.DTYPES[dtype]
         self.is16 = L.is16(self.dt)               # bf16 or fp16 MFMA operands (fp32 accumulate / residual stream / LN / softmax)
         self.tdt = _TORCH_DT[self.dt]
+        # bit masks over the Q-Former's layer kinds (X3_*) for the image pass and for the query-side passes: None = the default
+        # of the dtype, True / False = all / none, an int = that mask for both, a pair = (image mask, query mask)
+        if qformer_x3 is None:
+            qformer_x3 = X3_DEFAULT if self.dt == L.SPRC_F16 else 0
+        if isinstance(qformer_x3, (tuple, list)):
+            self.x3_image, self.x3_fuse = (int(v) for v in qformer_x3)
+        else:
+            self.x3_image = self.x3_fuse = X3_ALL if qformer_x3 is True else int(qformer_x3)
+        self.x3 = self.x3_image | self.x3_fuse      # what the weights are packed for
+        if self.x3 and self.dt != L.SPRC_F16:
+            raise ValueError("qformer_x3 (split-precision Q-Former) is a mode of the fp16 engine")
         self.max_batch = max_batch
         self._keep: List[torch.Tensor] = []
         self._ws: Dict[str, torch.Tensor] = {}
@@ -228,6 +252,18 @@ class Engine:
 
     def _lin(self, w: torch.Tensor, b: Optional[torch.Tensor], k_pad: Optional[int] = None) -> L.Linear:
         return L.Linear(self._w(w, k_pad).data_ptr(), None if b is None else self._f32(b).data_ptr())
+
+    def _lin_q(self, w: torch.Tensor, b: Optional[torch.Tensor], kind: int) -> L.Linear:
+        """A Q-Former linear of layer kind `kind` (X3_*): plain compute-dtype weights, or -- when the kind's bit is set in the
+        split-precision mask -- [W_hi | W_hi | W_lo] fp16, [out, 3 in]."""
+        if not (self.x3 & kind):
+            return self._lin(w, b)
+        w32 = w.detach().to(device=self.device, dtype=torch.float32)
+        hi = w32.to(torch.float16)
+        lo = (w32 - hi.float()).to(torch.float16)
+        w3 = torch.cat([hi, hi, lo], dim=1).contiguous()
+        self._keep.append(w3)
+        return L.Linear(w3.data_ptr(), None if b is None else self._f32(b).data_ptr())
 
     def _lin8(self, w: torch.Tensor, b: Optional[torch.Tensor]):
         """-> (Linear with e4m3fn weights, device pointer of the per-output-channel scales)"""
@@ -299,24 +335,24 @@ class Engine:
             b = f"{p}encoder.layer.{l}."
             ly = layers[l]
             a = b + "attention."
-            ly.qkv = self._lin(torch.cat([sd[a + "self.query.weight"], sd[a + "self.key.weight"], sd[a + "self.value.weight"]]).float(),
-                               torch.cat([sd[a + "self.query.bias"], sd[a + "self.key.bias"], sd[a + "self.value.bias"]]).float())
-            ly.attn_out = self._lin(sd[a + "output.dense.weight"], sd[a + "output.dense.bias"])
+            ly.qkv = self._lin_q(torch.cat([sd[a + "self.query.weight"], sd[a + "self.key.weight"], sd[a + "self.value.weight"]]).float(),
+                               torch.cat([sd[a + "self.query.bias"], sd[a + "self.key.bias"], sd[a + "self.value.bias"]]).float(), X3_QKV)
+            ly.attn_out = self._lin_q(sd[a + "output.dense.weight"], sd[a + "output.dense.bias"], X3_ATTN_OUT)
             ly.attn_ln_w, ly.attn_ln_b = ln(a + "output.LayerNorm")
             if l % q.cross_freq == 0:
                 c = b + "crossattention."
                 ly.has_cross, ly.cross_index = 1, n_cross
-                ly.cq = self._lin(sd[c + "self.query.weight"], sd[c + "self.query.bias"])
+                ly.cq = self._lin_q(sd[c + "self.query.weight"], sd[c + "self.query.bias"], X3_CROSS_Q)
                 ckv_w += [sd[c + "self.key.weight"].float(), sd[c + "self.value.weight"].float()]
                 ckv_b += [sd[c + "self.key.bias"].float(), sd[c + "self.value.bias"].float()]
-                ly.cross_out = self._lin(sd[c + "output.dense.weight"], sd[c + "output.dense.bias"])
+                ly.cross_out = self._lin_q(sd[c + "output.dense.weight"], sd[c + "output.dense.bias"], X3_CROSS_OUT)
                 ly.cross_ln_w, ly.cross_ln_b = ln(c + "output.LayerNorm")
                 n_cross += 1
-            ly.ffn_t_in = self._lin(sd[b + "intermediate.dense.weight"], sd[b + "intermediate.dense.bias"])
-            ly.ffn_t_out = self._lin(sd[b + "output.dense.weight"], sd[b + "output.dense.bias"])
+            ly.ffn_t_in = self._lin_q(sd[b + "intermediate.dense.weight"], sd[b + "intermediate.dense.bias"], X3_FFN_IN)
+            ly.ffn_t_out = self._lin_q(sd[b + "output.dense.weight"], sd[b + "output.dense.bias"], X3_FFN_OUT)
             ly.ffn_t_ln_w, ly.ffn_t_ln_b = ln(b + "output.LayerNorm")
-            ly.ffn_q_in = self._lin(sd[b + "intermediate_query.dense.weight"], sd[b + "intermediate_query.dense.bias"])
-            ly.ffn_q_out = self._lin(sd[b + "output_query.dense.weight"], sd[b + "output_query.dense.bias"])
+            ly.ffn_q_in = self._lin_q(sd[b + "intermediate_query.dense.weight"], sd[b + "intermediate_query.dense.bias"], X3_FFN_IN)
+            ly.ffn_q_out = self._lin_q(sd[b + "output_query.dense.weight"], sd[b + "output_query.dense.bias"], X3_FFN_OUT)
             ly.ffn_q_ln_w, ly.ffn_q_ln_b = ln(b + "output_query.LayerNorm")
         m = L.QformerModel()
         m.dtype, m.hidden, m.n_layers, m.heads, m.head_dim, m.ffn = self.dt, q.hidden, q.layers, q.heads, q.head_dim, q.ffn
@@ -326,13 +362,14 @@ class Engine:
         m.pos_emb = self._f32(sd[p + "embeddings.position_embeddings.weight"]).data_ptr()
         m.emb_ln_w, m.emb_ln_b = ln(p + "embeddings.LayerNorm")
         m.query_tokens = self._f32(sd["query_tokens"].reshape(q.num_query, q.hidden)).data_ptr()
-        m.ckv_all = self._lin(torch.cat([w.to(self.device) for w in ckv_w]), torch.cat([b_.to(self.device) for b_ in ckv_b]))
-        m.vision_proj = self._lin(sd["vision_proj.weight"], sd["vision_proj.bias"])
-        m.text_proj = self._lin(sd["text_proj.weight"], sd["text_proj.bias"])
+        m.ckv_all = self._lin_q(torch.cat([w.to(self.device) for w in ckv_w]), torch.cat([b_.to(self.device) for b_ in ckv_b]), X3_CKV)
+        m.vision_proj = self._lin_q(sd["vision_proj.weight"], sd["vision_proj.bias"], X3_HEADS)
+        m.text_proj = self._lin_q(sd["text_proj.weight"], sd["text_proj.bias"], X3_HEADS)
         # image-text-matching head of the stage-2 rerank (blip2_qformer_cir_rerank.py:88): fp32, two rows
         self.itm_w = self._f32(sd["itm_head.weight"]) if "itm_head.weight" in sd else None
         self.itm_b = self._f32(sd["itm_head.bias"]) if "itm_head.bias" in sd else None
         m.layers = C.cast(layers, C.POINTER(L.QfLayer))
+        m.x3, m.x3_image, m.x3_fuse = int(self.x3), int(self.x3_image), int(self.x3_fuse)
         self._qf_layers, self.qf = layers, m
         # learned prompt tokens of the training losses (align_prompt.py:76-79, :170-193)
         self.prompt_tokens = self._f32(sd["prompt_tokens"].reshape(q.num_query, q.hidden)) if "prompt_tokens" in sd else None
@@ -420,6 +457,26 @@ class Engine:
                                                None if f16 is None else f16[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
                                                _stream(self.device)), "sprc_qformer_fuse")
         return fusion, f16
+
+    @_on_device
+    def qformer_text(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        """feat[B,E] fp32 (unit rows) = normalize(text_proj(Qformer(text)[:, 0])): the Q-Former as a plain text encoder -- the
+        stage-1 query feature of the rerank model class (blip2_qformer_cir_rerank.py:373-390)."""
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        B = ids.shape[0]
+        if ids.shape != (B, self.cfg.max_txt_len) or mask.shape != ids.shape:
+            raise ValueError(f"input_ids/attention_mask must be [{B},{self.cfg.max_txt_len}]")
+        if not input_ids.is_cuda and (int(input_ids.min()) < 0 or int(input_ids.max()) >= self.cfg.qformer.vocab):
+            raise IndexError("token id out of range")
+        feat = torch.empty((B, self.cfg.embed_dim), dtype=torch.float32, device=self.device)
+        for s in range(0, B, self.max_batch):
+            n = min(self.max_batch, B - s)
+            ws = self._workspace("qf", n)
+            L.check(self.lib.sprc_qformer_text(C.byref(self.qf), ids[s:s + n].data_ptr(), mask[s:s + n].data_ptr(), n,
+                                               feat[s:s + n].data_ptr(), None, ws.data_ptr(), ws.numel(), _stream(self.device)),
+                    "sprc_qformer_text")
+        return feat
 
     # ---- stage-2 rerank (SURVEY.md section 8(f) N2) ------------------------------------------------------------------
     @property

@@ -50,7 +50,8 @@ def _decode_only(dataset):
         tf, inner = _decode_only(dataset.dataset)
         return tf, Subset(inner, dataset.indices)
     clone = copy.copy(dataset)
-    tf, clone.preprocess = dataset.preprocess, DecodeRGB()
+    tf = dataset.preprocess
+    clone.preprocess = DecodeRGB(getattr(tf, "ratio", 1.25), getattr(tf, "dim", 224))
     return tf, clone
 
 
@@ -124,8 +125,9 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     wanted = set() if keep_raw in (False, None) else (set(keep_raw) if subset else None)
     rows: Dict[int, torch.Tensor] = {}
     for batch_names, images in tqdm(loader):
-        if gpu_tf is not None:
-            images = torch.stack([gpu_tf(im) for im in images])
+        if gpu_tf is not None:       # uint8 images go through the GPU transform; items a worker already transformed (modes the GPU
+            from .data_utils import is_transformed      # path does not reproduce: palette, alpha, ...) are finished tensors
+            images = torch.stack([im.to(dev, non_blocking=True) if is_transformed(im) else gpu_tf(im) for im in images])
         images = images.to(dev, non_blocking=True)
         f, r = blip_model.extract_target_features(images, mode="mean")
         if raw_dtype is not None:
@@ -294,7 +296,6 @@ def cirr_test_dicts_from_sim(sim: torch.Tensor, ref_idx, group_idx, pairs_id, in
     g_rank = E.rank_of(sim.contiguous(), torch.from_numpy(group_idx)).cpu().numpy().astype(np.int64)
     if rerank_fn is not None:
         top = min(RERANK_TOP, N)
-        pos = np.broadcast_to(np.arange(N, dtype=np.int64), (len(pairs_id), N)).copy()     # placeholder ranks for non-top entries
         for s in range(0, len(pairs_id), 50):
             rows = list(range(s, min(s + 50, len(pairs_id))))
             cand = idx[rows, :top].astype(np.int64)

@@ -48,7 +48,7 @@ def _register(root: nn.Module, dotted: str, shape, device="cpu") -> None:
 class Blip2QformerCirAlignPrompt(nn.Module):
     PRETRAINED_MODEL_CONFIG_DICT = {k: k for k in MODEL_TYPES}     # align_prompt.py:38-42 ("coco" has no CIR use)
 
-    def __init__(self, model_type: str = "pretrain", compute_dtype: str = "bf16", rank_dtype: str = "fp32",
+    def __init__(self, model_type: str = "pretrain", compute_dtype: str = "fp16", rank_dtype: str = "fp32",
                  cfg: Optional[SprcConfig] = None, max_batch: int = 128, tokenizer=None, device="cpu"):
         super().__init__()
         self.cfg = cfg if cfg is not None else get_config(model_type)
@@ -141,8 +141,9 @@ class Blip2QformerCirAlignPrompt(nn.Module):
         target_feats = target_feats.to(device=dev, dtype=torch.float32).contiguous()
         if target_feats.dim() != 3 or target_feats.shape[1] != 32:
             raise ValueError("target_feats must be [N,32,embed_dim]")
-        if self.rank_dtype == "bf16":
-            return E.sim_max(fusion.to(torch.bfloat16), target_feats.to(torch.bfloat16))
+        if self.rank_dtype in ("bf16", "fp16"):
+            rdt = torch.bfloat16 if self.rank_dtype == "bf16" else torch.float16
+            return E.sim_max(fusion.to(rdt), target_feats.to(rdt))
         return E.sim_max(fusion, target_feats)
 
     @torch.no_grad()
@@ -205,8 +206,14 @@ class Blip2QformerCirAlignPrompt(nn.Module):
 
 # ---- registry + loader (lavis/common/registry.py:83-110, lavis/models/__init__.py:204-249) -----------
 class Blip2QformerCirRerank(Blip2QformerCirAlignPrompt):
-    """Checkpoint-key / registry alias of the stage-2 model class (blip2_qformer_cir_rerank.py:26-27): same trunk and
-    Q-Former, `inference_rerank` + `itm_head`; its frozen Q-Former copy (Fformer) is training-only and not loaded."""
+    """The stage-2 model class (blip2_qformer_cir_rerank.py:26-27): same trunk and Q-Former, `inference_rerank` + `itm_head`; its
+    frozen Q-Former copy (Fformer) is training-only and not loaded.  Its STAGE-1 score differs from align_prompt's: `inference`
+    (:373-397) ignores the reference image and the query tokens -- the Q-Former encodes the caption alone, text_proj of its [CLS]
+    row is matched against the gallery features."""
+
+    @torch.no_grad()
+    def fuse(self, reference_embeds, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
+        return self.engine().qformer_text(input_ids, attention_mask)      # reference_embeds unused, as in the reference (:373-390)
 
 
 _MODEL_REGISTRY: Dict[str, type] = {"blip2_cir_align_prompt": Blip2QformerCirAlignPrompt,

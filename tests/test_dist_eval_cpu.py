@@ -133,3 +133,15 @@ def test_owner_routing_and_offsets():
             assert (own[lo:hi] == r).all()
     offs = D.offsets_of([3, 0, 5])                       # an empty slice in the middle
     assert D.owner_from_offsets(torch.arange(8), offs).tolist() == [0, 0, 0, 2, 2, 2, 2, 2]
+
+
+def test_missing_targets_and_padding_slots_are_not_hits():
+    """a target that is not in the gallery maps to index -1, which is also the filler of unused top-k slots when the
+    gallery has fewer than k rows -- it must fail loudly (the reference asserts one label per query), never count as a hit."""
+    import pytest
+    from sprc_amd.dist_eval import _position, fiq_metrics_from_topk
+    top = np.array([[2, 0, 1, -1, -1], [1, 2, 0, -1, -1]], dtype=np.int64)            # a 3-image gallery, k = 5
+    assert _position(top, np.array([1, -1])).tolist() == [2, 5]
+    assert fiq_metrics_from_topk(top, np.array([1, 0])) == (100.0, 100.0)
+    with pytest.raises(AssertionError):
+        fiq_metrics_from_topk(top, np.array([1, -1]))

@@ -123,3 +123,68 @@ def test_bench_gpus2_spawns_two_ranks():
     ngpu = torch.cuda.device_count()
     assert ("gloo" in d["config"]["backend"]) == (ngpu < 2)
     assert abs(d["value"] - 2 * d["config"]["batch"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
+def _rccl_world1_worker(_rank, port, out):
+    """ONE rank, backend nccl (= RCCL) on cuda:0, SPRC_DIST_ALWAYS_EXCHANGE=1: the all_gather_into_tensor branch of
+    sprc_amd/dist.py (_all_gather_rows), all_gather_object on device, and the k x R merge run exactly as on an 8-GPU node."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["SPRC_DIST_ALWAYS_EXCHANGE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    from sprc_amd import dist as D
+    from sprc_amd import dist_eval as DE
+    from sprc_amd import engine as E
+    calls = {"n": 0}
+    real = dist.all_gather_into_tensor
+
+    def counting(o, i, group=None, **kw):
+        assert o.is_cuda and i.is_cuda                          # the payload stays on the device
+        calls["n"] += 1
+        return real(o, i, group=group, **kw)
+
+    dist.all_gather_into_tensor = counting
+    # (1) ShardedRanker directly: exchanges on vs off
+    g = torch.Generator(device="cuda").manual_seed(5)
+    feats = torch.nn.functional.normalize(torch.randn((300, 32, 256), generator=g, device="cuda"), dim=-1)
+    fusion = torch.nn.functional.normalize(torch.randn((40, 256), generator=g, device="cuda"), dim=-1)
+    listed = torch.randint(-1, 300, (40, 7), generator=torch.Generator().manual_seed(6))
+    on = D.ShardedRanker(feats, 1000).rank(fusion, 51, listed=listed + 1000 * (listed >= 0))
+    assert calls["n"] == 2                                       # fused vectors + ONE top-k / listed-score payload
+    off = D.ShardedRanker(feats, 1000, always_exchange=False).rank(fusion, 51, listed=listed + 1000 * (listed >= 0))
+    for a, b in zip(on, off):
+        assert torch.equal(a, b)
+    # (2) the sharded CIRR evaluation end to end
+    case = DC.build(0)
+    model = _model(case)
+    gallery = DC.Gallery(case["images"])
+    rel = DC.Relative(case["ref"], case["tgt"], case["groups"])
+    n0 = calls["n"]
+    cirr = DE.compute_cirr_val_metrics_sharded(rel, gallery, model, DC.TXT, num_workers=0, gallery_batch_size=16)
+    top, sub = DE.generate_cirr_test_dicts_sharded(DC.RelativeTest(case["ref"], case["tgt"], case["groups"]), gallery, model, DC.TXT,
+                                                   num_workers=0, gallery_batch_size=16)
+    torch.cuda.synchronize()
+    out["res"] = dict(cirr=cirr, top=top, sub=sub, gathers=calls["n"] - n0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_group_of_one_rank_runs_the_device_side_exchanges():
+    """VERDICT r2 missing #2: the `nccl` branch had never executed.  A world-size-1 RCCL group on the one GPU of the box, with the
+    exchanges forced on, against the single-process harness."""
+    from sprc_amd import harness as H
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_rccl_world1_worker, args=(_free_port(), out), nprocs=1, join=True)
+        res = dict(out["res"])
+    case = DC.build(0)
+    model = _model(case)
+    gallery = DC.Gallery(case["images"])
+    (feats, raw), names = H.extract_index_blip_features(gallery, model, batch_size=16, num_workers=0)
+    rel = DC.Relative(case["ref"], case["tgt"], case["groups"])
+    assert res["cirr"] == H.compute_cirr_val_metrics(rel, model, (feats, raw), names, DC.TXT)
+    want_top, want_sub = H.generate_cirr_test_dicts(DC.RelativeTest(case["ref"], case["tgt"], case["groups"]), model, (feats, raw),
+                                                    names, DC.TXT)
+    assert res["top"] == want_top and res["sub"] == want_sub
+    assert res["gathers"] == 4                                    # two evaluations x (fused vectors, top-k payload)

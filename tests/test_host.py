@@ -6,6 +6,7 @@ import tempfile
 from pathlib import Path
 
 import pytest
+import numpy as np
 import torch
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -185,5 +186,15 @@ def test_query_loaders_stay_in_the_main_process_and_gallery_workers_only_decode(
     # what fork-server workers have to unpickle
     assert isinstance(pickle.loads(pickle.dumps(targetpad_transform(1.25, 224))), HostTargetPad)
     assert isinstance(pickle.loads(pickle.dumps(DecodeRGB())), DecodeRGB)
+    # decode workers hand RGB / L images over as uint8 [H, W, 3]; modes the GPU transform does not reproduce (palette, alpha,
+    # bilevel: PIL resamples those in their own mode before converting) come back already transformed by the PIL path
+    from PIL import Image
+    from sprc_amd.data_utils import is_transformed
+    dec = DecodeRGB(1.25, 224)
+    rgb = Image.fromarray((np.arange(60 * 40 * 3) % 251).astype(np.uint8).reshape(40, 60, 3))
+    assert not is_transformed(dec(rgb)) and tuple(dec(rgb.convert("L")).shape) == (40, 60, 3)
+    for im in (rgb.convert("P"), rgb.convert("RGBA"), rgb.convert("1")):
+        out = dec(im)
+        assert is_transformed(out) and torch.equal(out, HostTargetPad(1.25, 224)(im))
     names, imgs = H._collate_ragged([("n0", torch.zeros(3, 4, 3, dtype=torch.uint8)), None, ("n1", torch.zeros(5, 2, 3, dtype=torch.uint8))])
     assert names == ["n0", "n1"] and [tuple(i.shape) for i in imgs] == [(3, 4, 3), (5, 2, 3)]

@@ -176,6 +176,12 @@ def test_rerank_matches_reference(golden_dir):
     np.testing.assert_allclose(prob.numpy(), g["prob"], atol=TOL, rtol=0)
     np.testing.assert_allclose(one.numpy(), g["prob_one"], atol=TOL, rtol=0)
     assert np.all((g["prob"] > 0) & (g["prob"] < 1)) and np.ptp(g["prob"]) > 0.02
+    # the rerank class's own stage-1 score: text only (blip2_qformer_cir_rerank.py:373-397)
+    with torch.no_grad():
+        feats, _ = O.extract_target_features(sd, cfg, images)
+        s1 = O.inference_rerank_stage1(sd, cfg, feats, ids, mask)
+    np.testing.assert_allclose(feats.numpy(), g["feats"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(s1.numpy(), g["sim_stage1"], atol=TOL, rtol=0)
 
 
 def test_training_losses_match_reference(golden_dir):

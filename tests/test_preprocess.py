@@ -68,6 +68,15 @@ def test_gpu_preprocessing_is_bit_identical(golden_dir):
     # PIL images and grayscale inputs go through _convert_image_to_rgb on the host
     gray = Image.fromarray(synth_image(260, 190, 7)[:, :, 0], mode="L")
     np.testing.assert_array_equal(tf(gray).cpu().numpy(), P.targetpad_transform(np.asarray(gray.convert("RGB"))))
+    # palette / alpha / bilevel images: PIL pads and resamples them in their OWN mode (NEAREST for P and 1, premultiplied alpha for
+    # RGBA / LA) before converting, which "convert first" does not reproduce -> routed through the host transform
+    from sprc_amd.data_utils import HostTargetPad
+    host = HostTargetPad(1.25, 224)
+    base = Image.fromarray(synth_image(300, 180, 11))
+    rgba = base.convert("RGBA")
+    rgba.putalpha(Image.fromarray((synth_image(300, 180, 12)[:, :, 0] // 2 + 64).astype(np.uint8), mode="L"))
+    for im in (base.convert("P", palette=Image.ADAPTIVE, colors=17), rgba, base.convert("LA"), base.convert("1")):
+        np.testing.assert_array_equal(tf(im).cpu().numpy(), host(im).numpy(), err_msg=im.mode)
     rng = np.random.default_rng(9)
     for _ in range(12):                                   # random shapes incl. extreme aspect ratios and tiny images
         w, h = int(rng.integers(8, 900)), int(rng.integers(8, 900))

@@ -57,6 +57,41 @@ def test_inference_rerank_matches_reference(golden_dir, dtype, tol):
     assert torch.equal(again.reshape(-1), prob)
 
 
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-6), ("fp16", 2e-4), ("bf16", 2e-3)])
+def test_rerank_class_stage1_inference_is_text_only(golden_dir, dtype, tol):
+    """`Blip2QformerCirRerank.inference` (blip2_qformer_cir_rerank.py:373-397) ignores the reference image: the Q-Former encodes the
+    caption alone (no query rows, text FFN) and text_proj of its [CLS] row is matched against the gallery features.  Golden: the
+    REFERENCE rerank class's `inference` on its own gallery features (the alias class used to inherit align_prompt's
+    two-pass fusion, so `--rerank` started from different top-50 candidates than the reference)."""
+    g = np.load(golden_dir / "rerank_eva.npz", allow_pickle=False)
+    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    model = Blip2QformerCirRerank(cfg=cfg, compute_dtype=dtype, max_batch=8)
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV)
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    model.tokenizer = _Tok(ids, mask)
+    images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]))
+    feats, raw = model.extract_target_features(images.to(DEV))
+    ref = torch.from_numpy(g["ref_index"]).to(DEV)
+    caps = [f"q{i}" for i in range(int(g["n_q"]))]
+    sim = model.inference(raw[ref], feats, caps)
+    other = model.inference(raw[(ref + 1) % raw.shape[0]], feats, caps)            # the reference image does not enter
+    assert torch.equal(sim, other)
+    err = np.abs(sim.cpu().numpy() - g["sim_stage1"]).max()
+    print(f"\n[rerank class stage 1, {dtype}] max|dsim| = {err:.2e}")
+    assert err < tol
+    if dtype == "fp32":
+        np.testing.assert_allclose(feats.cpu().numpy(), g["feats"], atol=1e-5, rtol=0)
+        # ... and it is NOT the align_prompt score
+        from sprc_amd.model import Blip2QformerCirAlignPrompt
+        ap = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=8)
+        ap.load_state_dict(sd, strict=False)
+        ap = ap.to(DEV)
+        ap.tokenizer = _Tok(ids, mask)
+        assert np.abs(ap.inference(raw[ref], feats, caps).cpu().numpy() - g["sim_stage1"]).max() > 1e-3
+
+
 def test_rerank_ragged_pairs_against_the_oracle():
     """13 pairs (not a multiple of anything), more pairs than max_batch, shared candidates, captions of every length."""
     cfg = get_config("pretrain_vitL", vit_depth=1)

@@ -22,7 +22,9 @@ images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]), planted=True)
 ref = torch.from_numpy(g["ref_index"]).to(DEV)
 ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
 e32 = E.Engine(cfg, sd, DEV, dtype="fp32", max_batch=32)
-e16 = E.Engine(cfg, sd, DEV, dtype=dtype, max_batch=32)
+x3 = None if len(sys.argv) < 3 else int(sys.argv[2], 0)             # fp16: split-precision mask of the Q-Former (engine.X3_*; default: the engine's)
+e16 = E.Engine(cfg, sd, DEV, dtype=dtype, max_batch=32, qformer_x3=x3)
+print(f"16-bit engine: {dtype}, split-precision Q-Former: {e16.x3}")
 
 
 def vit(eng):

@@ -96,3 +96,10 @@ with torch.no_grad():
         ACTIVE.update(ss)
         f = forward()
         print(f"group {name:18s}: {float((f - f0).norm() / f0.norm()):.2e}")
+    # what a split-operand (hi + lo fp16, ~22 bits) Q-Former leaves: GEMM operands exact, attention internals 16-bit
+    for name, ss in {"split GEMM operands; attention q,k,v,P 16-bit": ["O_qs", "O_ks", "O_vs", "P_s", "O_qx", "O_kx", "O_vx", "P_x"],
+                     "... and cross-attention q,k split too": ["O_qs", "O_ks", "O_vs", "P_s", "O_vx", "P_x"]}.items():
+        ACTIVE.clear()
+        ACTIVE.update(ss)
+        f = forward()
+        print(f"{name}: {float((f - f0).norm() / f0.norm()):.2e}  max abs {float((f - f0).abs().max()):.2e}")
