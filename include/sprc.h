@@ -249,6 +249,8 @@ typedef struct {
     int32_t fp8;                                /* 1: dtype is SPRC_BF16 and the three big GEMMs of every block run on fp8 operands */
     float* calib_amax;                          /* optional device array [depth*3] (bf16 model only): running max |x| of the qkv / fc1 /
                                                  * fc2 inputs, updated by sprc_vit_forward -- the calibration pass of the fp8 scales */
+    float* pre_ln_out;                          /* optional device array [B, tokens, width] fp32: receives the INPUT of ln_vision (the ViT's last
+                                                 * residual stream) -- what the training step needs for ln_vision's gradient (blip2.py:81) */
 } sprc_vit_model;
 
 typedef struct {
@@ -343,7 +345,8 @@ int sprc_preprocess_targetpad(const uint8_t* src, int32_t src_h, int32_t src_w, 
 /* ------------------------------------------------------------------------------------------
  * Training forward: the three losses of Blip2QformerCirAlignPrompt.forward,
  * lavis/models/blip2_models/blip2_qformer_cir_align_prompt.py:95-200 (eval semantics: dropout = identity).
- * FORWARD ONLY: no backward kernels; sprc_amd.model.forward returns the losses without autograd history.
+ * The backward kernels are at the end of this file; sprc_amd/train.py sequences forward + backward, sprc_amd.model.forward
+ * wraps them in a torch.autograd.Function.
  * ---------------------------------------------------------------------------------------- */
 
 /* sprc_qformer_fuse + loss_align: additionally writes loss_align[0] = mse(mean over the query rows of the PASS-1 output,
@@ -370,6 +373,54 @@ int sprc_contrastive_ce(const float* sim, int64_t ld, int32_t B, float temp, flo
 /* loss[0] = mse(mean_j h[b, j, :], mean_j prompt[j, :]), j < Lq; h fp32 with `sample_stride` elements between samples. */
 int sprc_align_mse(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* prompt, int32_t B, float* loss,
                    sprc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Training BACKWARD: the kernels sprc_amd/train.py sequences into the gradient of
+ * Blip2QformerCirAlignPrompt.forward (align_prompt.py:95-200) for blip_fine_tune_2.py:293-304.  The ViT is frozen in the
+ * reference (align_prompt.py:64-69): what trains is the Q-Former, ln_vision, the ITC heads, query / prompt tokens and temp.
+ * All fp32.  Products run on sprc_gemm (exact-fp32 MFMA) through transposed operand copies: dX = dY . W as
+ * sprc_gemm(A = dY, W = W^T), dW (+)= dY^T . X as sprc_gemm(A = dY^T, W = X^T, resid = dW).
+ * ---------------------------------------------------------------------------------------- */
+
+/* dst[c, r] = src[r, c]; leading dimensions in elements. */
+int sprc_transpose_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int32_t rows, int32_t cols, sprc_stream s);
+/* out[n] (+)= sum_m x[m, n]  (bias gradients; fixed summation order). */
+int sprc_colsum_f32(const float* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, sprc_stream s);
+/* y = x Phi(x) (exact erf form, Qformer.py:482-490 ACT2FN["gelu"]) and dx = dy (Phi(x) + x phi(x)). */
+int sprc_gelu_fwd(const float* x, float* y, size_t n, sprc_stream s);
+int sprc_gelu_bwd(const float* x, const float* dy, float* dx, size_t n, sprc_stream s);
+/* LayerNorm backward from the INPUT x: dx (optional) = rstd (g - mean g - xhat mean(g xhat)), g = dy gamma; dgamma += sum dy xhat,
+ * dbeta += sum dy (per-block partials in ws, reduced in block order). */
+size_t sprc_layernorm_bwd_workspace_bytes(int32_t M, int32_t D);
+int sprc_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t lddy, float eps, int32_t M, int32_t D,
+                       float* dx, int64_t lddx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, sprc_stream s);
+/* Backward of sprc_attention (fp32, head_dim 64, same token layout): dq, dk, dv from dout; probabilities are recomputed.
+ * scratch: 2 * B * H * Tq * Tk floats. */
+typedef struct {
+    int32_t B, H, Tq, Tk, head_dim;
+    const float *q, *k, *v, *dout; int64_t ldq, ldk, ldv, lddo;
+    const float* key_mask; float scale;
+    float *dq, *dk, *dv; int64_t lddq, lddk, lddv;
+    void* scratch; size_t scratch_bytes;
+} sprc_attention_bwd_args;
+int sprc_attention_bwd(const sprc_attention_bwd_args* a, sprc_stream s);
+/* The rows sprc_qformer_embed normalises, WITHOUT the LayerNorm (pre [B, Lq+Lt, hidden]), and the scatter of their gradient:
+ * dquery[b * dq_bstride + row] += (dq_bstride 0: summed over the batch), dword[id] +=, dpos[position] += (atomic adds). */
+int sprc_qformer_embed_rows(const sprc_qformer_embed_args* a, float* pre, sprc_stream s);
+int sprc_qformer_embed_bwd(const sprc_qformer_embed_args* a, const float* dpre, float* dquery, int64_t dq_bstride, float* dword, float* dpos,
+                           sprc_stream s);
+/* sim[b, n] = max_j <fusion[b], feats[n, j]>: dfusion[b] += sum_n dsim[b, n] feats[n, j*], dfeats[n, j*] += dsim[b, n] fusion[b],
+ * j* = the first argmax (torch.max); jstar: int32 [B, N] scratch. */
+int sprc_sim_max_bwd(const float* fusion, const float* feats, const float* dsim, int32_t B, int32_t N, int32_t J, int32_t E, float* dfusion,
+                     float* dfeats, int32_t* jstar, sprc_stream s);
+/* Backward of sprc_contrastive_ce scaled by `grad`: dsim [B, B] (written), dtemp[0] += (optional). */
+int sprc_contrastive_ce_bwd(const float* sim, int64_t ld, int32_t B, float temp, float grad, float* dsim, float* dtemp, sprc_stream s);
+/* Backward of sprc_l2norm_rows from its input x. */
+int sprc_l2norm_bwd(const float* x, int64_t ldx, const float* dy, int64_t lddy, float* dx, int64_t lddx, int32_t M, int32_t D, sprc_stream s);
+/* Backward of sprc_align_mse scaled by `grad` into the first Lq rows of every sample of dh (+=); the prompt side is detached
+ * (align_prompt.py:193). */
+int sprc_align_mse_bwd(const float* h, int64_t sample_stride, int32_t Lq, int32_t D, const float* prompt, int32_t B, float grad, float* dh,
+                       int64_t d_stride, sprc_stream s);
 
 #ifdef __cplusplus
 }

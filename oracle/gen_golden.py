@@ -313,9 +313,25 @@ def rerank_goldens(out: Path, seed: int = 2):
     print(f"wrote {out}: prob {prob.numpy().round(4).tolist()}")
 
 
+GRAD_WEIGHTS = {"loss_itc": 1.0, "loss_rtc": 0.4, "loss_align": 0.4}      # blip_fine_tune_2.py:293-299 with its defaults (:379-380)
+
+
+def grad_functionals(name: str, g: torch.Tensor) -> np.ndarray:
+    """A gradient tensor as 12 numbers (the Q-Former's gradients are 700 MB): [||g||, <g, r1>, <g, r2>, sum(g), 8 probe entries];
+    r1, r2 ~ N(0, 1) and the probe positions come from a generator seeded by crc32(name).  Any error pattern moves <g, r>."""
+    import zlib
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    flat = g.detach().double().flatten()
+    r = torch.randn((2, flat.numel()), generator=gen, dtype=torch.float32).double()
+    probe = torch.randint(0, flat.numel(), (8,), generator=gen)
+    return np.concatenate([[float(flat.norm())], (r @ flat).numpy(), [float(flat.sum())], flat[probe].numpy()])
+
+
 def train_goldens(out: Path, seed: int = 4):
-    """Training forward (N4): the REFERENCE's Blip2QformerCirAlignPrompt.forward (align_prompt.py:95-200) in eval mode on 5
-    (reference, target, caption) triplets, depth-2 ViT-g + the full Q-Former: the three losses."""
+    """Training forward + backward (N4): the REFERENCE's Blip2QformerCirAlignPrompt.forward (align_prompt.py:95-200) in eval mode on 5
+    (reference, target, caption) triplets, depth-2 ViT-g + the full Q-Former: the three losses, and the gradient of
+    loss_itc + 0.4 loss_rtc + 0.4 loss_align (blip_fine_tune_2.py:293-304) with respect to every trainable tensor, as
+    `grad_functionals`; tensors the reference leaves without a gradient (itm_head, the LM head) are listed."""
     cfg = get_config("pretrain", vit_depth=2)
     sd = synth.make_state_dict(cfg, seed=seed)
     model = ref_import.build_reference_model(cfg, sd)
@@ -325,10 +341,28 @@ def train_goldens(out: Path, seed: int = 4):
     model.tokenizer.set_next(ids, mask)
     with torch.no_grad():
         out_d = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
+    model.tokenizer.set_next(ids, mask)
+    model.zero_grad()
+    losses = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
+    total = sum(GRAD_WEIGHTS[k] * v for k, v in losses.items())
+    total.backward()
+    grads, no_grad, frozen = {}, [], []
+    for name, p_ in model.named_parameters():
+        if not p_.requires_grad:
+            frozen.append(name)
+        elif p_.grad is None:
+            no_grad.append(name)
+        elif name in sd or name == "temp":
+            grads[name] = grad_functionals(name, p_.grad)
+        else:
+            no_grad.append(name + " (not in the synthetic state dict)")
+    assert all(n.startswith("visual_encoder.") for n in frozen)
     np.savez_compressed(out, model_type="pretrain", vit_depth=2, seed=seed, batch=B, image_probe=_np(images[:, :, 0, :4]),
                         input_ids=ids.numpy(), attention_mask=mask.numpy(),
+                        grad_names=np.array(list(grads)), grad_values=np.stack(list(grads.values())),
+                        no_grad_names=np.array(no_grad), grad_weights=json.dumps(GRAD_WEIGHTS),
                         **{k: np.float64(v.item()) for k, v in out_d.items()})
-    print(f"wrote {out}:", {k: round(v.item(), 6) for k, v in out_d.items()})
+    print(f"wrote {out}:", {k: round(v.item(), 6) for k, v in out_d.items()}, f"{len(grads)} gradient tensors, no grad: {no_grad[:6]} ...")
 
 
 def caption_goldens(out: Path):

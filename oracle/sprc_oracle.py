@@ -313,8 +313,26 @@ def training_losses(sd: SD, cfg, image: Tensor, target: Tensor, input_ids: Tenso
     t_only = qformer_text_only(sd, cfg, prompt, input_ids, mask)                              # :170-179
     t_feat = _normalize(F.linear(t_only[:, 0, :], sd["text_proj.weight"].float(), sd["text_proj.bias"].float()))
     loss_rtc = F.cross_entropy(similarity(t_feat, target_feats) / temp, targets)              # :181-190
-    loss_align = F.mse_loss(p1[:, :Lq, :].mean(1), prompt.mean(1))                            # :192-193
+    loss_align = F.mse_loss(p1[:, :Lq, :].mean(1), prompt.clone().detach().mean(1))           # :192-193 (the prompt side is detached)
     return {"loss_itc": loss_itc, "loss_rtc": loss_rtc, "loss_align": loss_align}
+
+
+TRAIN_LOSS_WEIGHTS = {"loss_itc": 1.0, "loss_rtc": 0.4, "loss_align": 0.4}    # blip_fine_tune_2.py:293-299 with its defaults (:379-380)
+
+
+def training_gradients(sd: SD, cfg, image: Tensor, target: Tensor, input_ids: Tensor, attention_mask: Tensor,
+                       weights: Optional[Dict[str, float]] = None) -> Tuple[Dict[str, Tensor], Dict[str, Tensor]]:
+    """-> (losses, {name: d(loss_itc + w_rtc loss_rtc + w_align loss_align) / d tensor}) for every tensor the reference trains
+    (blip_fine_tune_2.py:257-262: everything with requires_grad, i.e. all but the ViT trunk, align_prompt.py:64-69): torch autograd
+    over `training_losses`, the restatement of `forward` above.  Tensors `forward` does not touch (itm_head, the LM head) get none."""
+    weights = weights or TRAIN_LOSS_WEIGHTS
+    leaf = {k: (v.detach().float().clone().requires_grad_(not k.startswith("visual_encoder.")) if v.is_floating_point() else v)
+            for k, v in sd.items()}
+    losses = training_losses(leaf, cfg, image, target, input_ids, attention_mask)
+    total = sum(weights[k] * v for k, v in losses.items())
+    total.backward()
+    grads = {k: v.grad for k, v in leaf.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}
+    return {k: v.detach() for k, v in losses.items()}, grads
 
 
 def inference_rerank(sd: SD, cfg, reference_embeds: Tensor, target_embeds: Tensor, input_ids: Tensor,

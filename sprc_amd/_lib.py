@@ -59,6 +59,13 @@ class QformerEmbedArgs(C.Structure):
                 ("gamma", vp), ("beta", vp), ("eps", f32), ("y32", vp), ("y16", vp), ("no_img", i32)]
 
 
+class AttentionBwdArgs(C.Structure):
+    _fields_ = [("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("head_dim", i32),
+                ("q", vp), ("k", vp), ("v", vp), ("dout", vp), ("ldq", i64), ("ldk", i64), ("ldv", i64), ("lddo", i64),
+                ("key_mask", vp), ("scale", f32), ("dq", vp), ("dk", vp), ("dv", vp), ("lddq", i64), ("lddk", i64), ("lddv", i64),
+                ("scratch", vp), ("scratch_bytes", sz)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", i64), ("busy_ms", C.c_double)]
 
@@ -81,7 +88,7 @@ class VitModel(C.Structure):
                 ("act", i32), ("tokens", i32), ("patch_size", i32), ("image", i32), ("patch_k_pad", i32),
                 ("has_ln_pre", i32), ("ln_eps", f32), ("ln_vision_eps", f32), ("patch", Linear),
                 ("cls", vp), ("pos", vp), ("ln_pre_w", vp), ("ln_pre_b", vp), ("ln_vision_w", vp), ("ln_vision_b", vp),
-                ("layers", C.POINTER(VitLayer)), ("fp8", i32), ("calib_amax", vp)]
+                ("layers", C.POINTER(VitLayer)), ("fp8", i32), ("calib_amax", vp), ("pre_ln_out", vp)]
 
 
 class QfLayer(C.Structure):
@@ -137,6 +144,19 @@ SIGNATURES = {
     "sprc_qformer_text": (i32, [C.POINTER(QformerModel), vp, vp, i32, vp, vp, vp, sz, vp]),
     "sprc_contrastive_ce": (i32, [vp, i64, i32, f32, vp, vp]),
     "sprc_align_mse": (i32, [vp, i64, i32, i32, vp, i32, vp, vp]),
+    "sprc_transpose_f32": (i32, [vp, i64, vp, i64, i32, i32, vp]),
+    "sprc_colsum_f32": (i32, [vp, i64, i32, i32, vp, i32, vp]),
+    "sprc_gelu_fwd": (i32, [vp, vp, sz, vp]),
+    "sprc_gelu_bwd": (i32, [vp, vp, vp, sz, vp]),
+    "sprc_layernorm_bwd_workspace_bytes": (sz, [i32, i32]),
+    "sprc_layernorm_bwd": (i32, [vp, i64, vp, vp, i64, f32, i32, i32, vp, i64, vp, vp, vp, sz, vp]),
+    "sprc_attention_bwd": (i32, [C.POINTER(AttentionBwdArgs), vp]),
+    "sprc_qformer_embed_rows": (i32, [C.POINTER(QformerEmbedArgs), vp, vp]),
+    "sprc_qformer_embed_bwd": (i32, [C.POINTER(QformerEmbedArgs), vp, vp, i64, vp, vp, vp]),
+    "sprc_sim_max_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "sprc_contrastive_ce_bwd": (i32, [vp, i64, i32, f32, f32, vp, vp, vp]),
+    "sprc_l2norm_bwd": (i32, [vp, i64, vp, i64, vp, i64, i32, i32, vp]),
+    "sprc_align_mse_bwd": (i32, [vp, i64, i32, i32, vp, i32, f32, vp, i64, vp]),
     "sprc_preprocess_workspace_bytes": (sz, [i32, i32, f32, i32]),
     "sprc_preprocess_targetpad": (i32, [vp, i32, i32, i64, f32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp, sz, vp]),
 }

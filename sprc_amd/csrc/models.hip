@@ -442,6 +442,14 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
             }
         }
     }
+    if (m->pre_ln_out != nullptr) {
+        SPRC_REQUIRE(!fuse_add, "sprc_vit_forward: pre_ln_out is not available with SPRC_FUSE_ADD");
+        for (int i = 0; i < nparts; ++i) {
+            const size_t r0 = (size_t)(parts[i].x - v.x);
+            SPRC_REQUIRE(hipMemcpyAsync(m->pre_ln_out + r0, parts[i].x, (size_t)parts[i].Mp * D * sizeof(float), hipMemcpyDeviceToDevice,
+                                        parts[i].ps) == hipSuccess, "sprc_vit_forward: copy of the pre-LayerNorm stream failed");
+        }
+    }
     for (int i = 0; i < nparts; ++i)
         RUN(lnorm(parts[i].ps, dt, parts[i].Mp, D, parts[i].x, m->ln_vision_w, m->ln_vision_b, m->ln_vision_eps, parts[i].raw, nullptr,
                   ID_MAP, fuse_add && m->depth > 0 ? parts[i].h : nullptr));

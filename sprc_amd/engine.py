@@ -402,19 +402,27 @@ class Engine:
 
     # ---- forward passes ----------------------------------------------------------------------
     @_on_device
-    def vit_forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """raw[B,257,D] fp32 = ln_vision(ViT(images))."""
+    def vit_forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, pre_ln_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """raw[B,257,D] fp32 = ln_vision(ViT(images)).  pre_ln_out (optional, fp32 [B*257, D] or [B,257,D]): receives ln_vision's INPUT
+        (the training step differentiates ln_vision, sprc_amd/train.py)."""
         v = self.cfg.vit
         images = images.to(device=self.device, dtype=torch.float32).contiguous()
         B = images.shape[0]
         if tuple(images.shape[1:]) != (3, v.image, v.image):
             raise ValueError(f"Input image size ({images.shape[2]}*{images.shape[3]}) doesn't match model ({v.image}*{v.image}).")
         raw = out if out is not None else torch.empty((B, v.tokens, v.width), dtype=torch.float32, device=self.device)
-        for s in range(0, B, self.max_batch):
-            n = min(self.max_batch, B - s)
-            ws = self._workspace("vit", n)
-            L.check(self.lib.sprc_vit_forward(C.byref(self.vit), images[s:s + n].data_ptr(), n, raw[s:s + n].data_ptr(),
-                                              ws.data_ptr(), ws.numel(), _stream(self.device)), "sprc_vit_forward")
+        if pre_ln_out is not None:
+            assert pre_ln_out.dtype == torch.float32 and pre_ln_out.is_contiguous() and pre_ln_out.numel() == B * v.tokens * v.width
+        try:
+            for s in range(0, B, self.max_batch):
+                n = min(self.max_batch, B - s)
+                ws = self._workspace("vit", n)
+                if pre_ln_out is not None:
+                    self.vit.pre_ln_out = pre_ln_out.data_ptr() + s * v.tokens * v.width * 4
+                L.check(self.lib.sprc_vit_forward(C.byref(self.vit), images[s:s + n].data_ptr(), n, raw[s:s + n].data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), _stream(self.device)), "sprc_vit_forward")
+        finally:
+            self.vit.pre_ln_out = None
         return raw
 
     @_on_device

@@ -28,6 +28,7 @@ import torch.nn as nn
 from . import _lib as L
 from . import engine as E
 from . import synth
+from .train import TrainStep
 from .config import MODEL_TYPES, SprcConfig, get_config
 
 
@@ -42,7 +43,8 @@ def _register(root: nn.Module, dotted: str, shape, device="cpu") -> None:
         if p not in mod._modules:
             mod.add_module(p, _Node())
         mod = mod._modules[p]
-    mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape, device=device), requires_grad=False))
+    # what the reference trains: everything but the ViT trunk (align_prompt.py:64-69)
+    mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape, device=device), requires_grad=not dotted.startswith("visual_encoder.")))
 
 
 class Blip2QformerCirAlignPrompt(nn.Module):
@@ -56,7 +58,7 @@ class Blip2QformerCirAlignPrompt(nn.Module):
         self.max_txt_len = self.cfg.max_txt_len
         for name, shape, _ in synth.param_specs(self.cfg):
             _register(self, name, shape, device)
-        self.register_parameter("temp", nn.Parameter(0.07 * torch.ones([], device=device), requires_grad=False))
+        self.register_parameter("temp", nn.Parameter(0.07 * torch.ones([], device=device), requires_grad=True))
         self._engine: Optional[E.Engine] = None
         self._tokenizer = tokenizer
         self.training = False
@@ -192,16 +194,50 @@ class Blip2QformerCirAlignPrompt(nn.Module):
                                  tok.attention_mask.repeat_interleave(T, dim=0))
         return prob.view(nq, T)
 
-    @torch.no_grad()
     def forward(self, samples):
-        """Training forward, align_prompt.py:95-200: {"image", "target", "text_input"} -> {"loss_itc", "loss_rtc", "loss_align"}
-        computed by the HIP engine with eval semantics (dropout = identity).  FORWARD ONLY: the losses carry no autograd
-        history -- there are no backward kernels, so `blip_fine_tune_2.py`'s `.backward()` has
-        nothing to differentiate; use it for loss evaluation / monitoring."""
+        """Training step, align_prompt.py:95-200: {"image", "target", "text_input"} -> {"loss_itc", "loss_rtc", "loss_align"}, eval
+        semantics (dropout = identity).  With autograd enabled the losses are outputs of a torch.autograd.Function whose backward
+        runs the HIP backward kernels (sprc_amd/train.py) and hands every trainable parameter its gradient, so the reference's loop
+        (blip_fine_tune_2.py:293-304: weighted sum, `scaler.scale(loss).backward()`, AdamW step) runs as written; the training graph
+        is evaluated on the exact-fp32 engine.  Under torch.no_grad() the losses come from the inference engine in its compute dtype."""
         image, target, text = samples["image"], samples["target"], samples["text_input"]
         tok = self.tokenizer(list(text), padding="max_length", truncation=True, max_length=self.max_txt_len,
                              return_tensors="pt").to(self.device)
-        return self.engine().training_losses(image, target, tok.input_ids, tok.attention_mask, temp=float(self.temp))
+        if not torch.is_grad_enabled():
+            with torch.no_grad():
+                return self.engine().training_losses(image, target, tok.input_ids, tok.attention_mask, temp=float(self.temp))
+        names = [n for n, p_ in self.named_parameters() if p_.requires_grad and TrainStep._trains(n)]
+        params = dict(self.named_parameters())
+        out = _TrainFn.apply(self, image, target, tok.input_ids, tok.attention_mask, names, *[params[n] for n in names])
+        self._engine = None                       # the optimizer is about to move the weights the inference engine has packed
+        return {"loss_itc": out[0], "loss_rtc": out[1], "loss_align": out[2]}
+
+    def _train_engine(self) -> E.Engine:
+        """fp32 engine for the frozen ViT trunk of the training step (built once: the trunk does not train)."""
+        if getattr(self, "_tengine", None) is None:
+            if self.device.type != "cuda":
+                raise L.SprcError("training runs on the MI355X HIP engine only; move the model to a GPU with .to('cuda') (there is no CPU fallback)")
+            self._tengine = E.Engine(self.cfg, dict(self.state_dict()), self.device, dtype="fp32", max_batch=self.max_batch)
+        return self._tengine
+
+
+class _TrainFn(torch.autograd.Function):
+    """losses = f(trainable parameters): forward and backward are the HIP training step (sprc_amd/train.py)."""
+
+    @staticmethod
+    def forward(ctx, model, image, target, input_ids, attention_mask, names, *params):
+        P = {n: p_.detach() for n, p_ in model.named_parameters()}
+        step = TrainStep(model.cfg, {n: t.float().contiguous() for n, t in P.items()}, model._train_engine())
+        losses = step.forward(image.to(model.device), target.to(model.device), input_ids, attention_mask)
+        ctx.step, ctx.names = step, names
+        return losses["loss_itc"].clone(), losses["loss_rtc"].clone(), losses["loss_align"].clone()
+
+    @staticmethod
+    def backward(ctx, g_itc, g_rtc, g_align):
+        w = {"loss_itc": float(g_itc), "loss_rtc": float(g_rtc), "loss_align": float(g_align)}     # (GradScaler's scale rides in here)
+        G = ctx.step.backward(w)
+        ctx.step = None
+        return (None,) * 6 + tuple(G[n].view_as(G[n]) for n in ctx.names)
 
 
 # ---- registry + loader (lavis/common/registry.py:83-110, lavis/models/__init__.py:204-249) -----------

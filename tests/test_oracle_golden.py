@@ -159,6 +159,51 @@ def test_planted_structure_case_matches_reference(golden_dir):
     assert top == dicts["top"] and sub == dicts["sub"]
 
 
+def _grad_functionals(name, g):
+    import zlib
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    flat = g.detach().double().flatten().cpu()
+    r = torch.randn((2, flat.numel()), generator=gen, dtype=torch.float32).double()
+    probe = torch.randint(0, flat.numel(), (8,), generator=gen)
+    return np.concatenate([[float(flat.norm())], (r @ flat).numpy(), [float(flat.sum())], flat[probe].numpy()])
+
+
+def check_gradients_against_golden(g, grads, rel_tol):
+    """grads: {state-dict name: tensor}; golden rows are [||g||, <g, r1>, <g, r2>, sum g, 8 probes] (oracle/gen_golden.py).  Every
+    functional within rel_tol x ||g|| x (its natural scale: sqrt(n) for sum g, 1 for the rest)."""
+    names = [str(n) for n in g["grad_names"]]
+    assert set(names) == set(grads), (sorted(set(names) ^ set(grads))[:8])
+    worst = 0.0
+    for name, want in zip(names, g["grad_values"]):
+        got = _grad_functionals(name, grads[name])
+        if want[0] < 1e-8:              # key biases: the softmax is invariant to a per-query shift, their gradient is rounding noise
+            assert got[0] < 1e-6, f"{name}: ||g|| = {got[0]:.2e}, the reference's is {want[0]:.2e} (mathematically zero)"
+            continue
+        norm = want[0]
+        scale = np.array([1.0, 1.0, 1.0, np.sqrt(grads[name].numel())] + [1.0] * 8) * norm
+        err = np.abs(got - want) / scale
+        worst = max(worst, float(err.max()))
+        assert err.max() < rel_tol, f"{name}: functional error {err.max():.2e} of ||g|| = {norm:.3e} ({got[:4]} vs {want[:4]})"
+    return worst
+
+
+def test_training_gradients_match_reference(golden_dir):
+    """N4 backward: torch autograd over the oracle's `training_losses` == the reference's forward + backward (eval mode) on the
+    train_eva triplets, for all 337 trainable tensors (incl. ln_vision, temp, prompt_tokens, both embedding tables)."""
+    g = np.load(golden_dir / "train_eva.npz", allow_pickle=False)
+    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    B = int(g["batch"])
+    images = synth.make_images(2 * B, seed=int(g["seed"]))
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    losses, grads = O.training_gradients(sd, cfg, images[:B], images[B:], ids, mask)
+    for k in ("loss_itc", "loss_rtc", "loss_align"):
+        assert abs(float(losses[k]) - float(g[k])) < 1e-5
+    worst = check_gradients_against_golden(g, grads, 1e-4)
+    assert all(not n.startswith("visual_encoder.") for n in grads) and "ln_vision.weight" in grads and "temp" in grads
+    print(f"\n[oracle training gradients] worst functional error / ||g|| = {worst:.2e} over {len(grads)} tensors")
+
+
 def test_rerank_matches_reference(golden_dir):
     """N2: the oracle's inference_rerank against the reference's Blip2QformerCirRerank.inference_rerank (514-token
     cross-attention + itm_head + softmax), batched (3 queries x 4 candidates) and the single-query branch."""
