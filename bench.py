@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=10, help="record per-launch HIP events on every Nth timed step, starting with the first (0 = never)")
     ap.add_argument("--vit-streams", type=int, default=1, help="2 = pipeline the two halves of a batch on two streams inside sprc_vit_forward (+4 %% images/s; per-kernel timings then overlap)")
+    ap.add_argument("--qf-streams", type=int, default=2, help="2 = the gallery-side and the query-side Q-Former passes of a step run on two streams")
     ap.add_argument("--cpu-images", type=int, default=32, help="size of the bounded CPU-baseline sample (~15 s of CPU work on 16 cores)")
     return ap.parse_args()
 
@@ -202,12 +203,26 @@ def main():
     ranker = ShardedRanker(gallery, index_base=lo_g)
     raw = torch.empty((BATCH, cfg.vit.tokens, cfg.vit.width), dtype=torch.float32, device=dev)
 
+    # The gallery-side Q-Former pass (128 x 32 rows: small, latency-bound launches that leave most CUs idle) and the query-side fusion
+    # passes are independent until the ranking: they run on two streams (--qf-streams 1 serialises them for A/B runs).
+    side = torch.cuda.Stream(device=dev) if a.qf_streams >= 2 else None
+    main = torch.cuda.current_stream(dev)
+
     def step(i: int):
         eng.vit_forward(images, out=raw)                                          # R3/R4
-        feats, _ = eng.qformer_image(raw)                                         # R5(i) + vision_proj
         lo = (i * BATCH) % (GALLERY - BATCH)
-        gallery[lo:lo + BATCH].copy_(feats)                                       # resident gallery slice of this batch
-        fusion, _ = eng.qformer_fuse(raw.index_select(0, ref_slot), ids, mask)    # R6 fusion half
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                feats, _ = eng.qformer_image(raw)                                 # R5(i) + vision_proj
+                gallery[lo:lo + BATCH].copy_(feats)                               # resident gallery slice of this batch
+                feats.record_stream(side)
+            fusion, _ = eng.qformer_fuse(raw.index_select(0, ref_slot), ids, mask)    # R6 fusion half
+            main.wait_stream(side)
+        else:
+            feats, _ = eng.qformer_image(raw)
+            gallery[lo:lo + BATCH].copy_(feats)
+            fusion, _ = eng.qformer_fuse(raw.index_select(0, ref_slot), ids, mask)
         return ranker.rank(fusion, TOPK)                                          # R6 similarity + R7 top-k (+ exchanges)
 
     def barrier():
@@ -286,7 +301,7 @@ def main():
                                    f"{'ViT-g' if a.backbone == 'pretrain' else 'ViT-L'} {a.dtype}, batch {BATCH}; step = encode {BATCH} images + "
                                    f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
-                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams,
+                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_streams": a.qf_streams,
                        "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and backend == "nccl" else None),
                        "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNELS[a.dtype], "achieved": round(ach, 1), "peak": peak,

@@ -392,7 +392,7 @@ class Engine:
 
     # ---- workspaces ------------------------------------------------------------------------
     def _workspace(self, kind: str, B: int) -> torch.Tensor:
-        fn = self.lib.sprc_vit_workspace_bytes if kind == "vit" else self.lib.sprc_qformer_workspace_bytes
+        fn = self.lib.sprc_vit_workspace_bytes if kind == "vit" else self.lib.sprc_qformer_workspace_bytes      # "qf", "qf_image"
         need = int(fn(C.byref(self.vit if kind == "vit" else self.qf), B))
         ws = self._ws.get(kind)
         if ws is None or ws.numel() < need:
@@ -436,7 +436,7 @@ class Engine:
         f16 = torch.empty((B, Lq, E), dtype=self.tdt, device=self.device) if self.is16 else None
         for s in range(0, B, self.max_batch):
             n = min(self.max_batch, B - s)
-            ws = self._workspace("qf", n)
+            ws = self._workspace("qf_image", n)          # its own workspace: the image pass may run on a side stream beside a fusion pass
             L.check(self.lib.sprc_qformer_image(C.byref(self.qf), raw[s:s + n].data_ptr(), n, feats[s:s + n].data_ptr(),
                                                 None if f16 is None else f16[s:s + n].data_ptr(), ws.data_ptr(), ws.numel(),
                                                 _stream(self.device)), "sprc_qformer_image")

@@ -98,7 +98,52 @@ class RawStore:
         return sum(r.numel() * r.element_size() for r in self.rows.values())
 
 
-def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, batch_size: int = 64, num_workers: int = 2,
+class _ThreadLoader:
+    """Decode-only gallery loader on a THREAD pool: yields (names, [uint8 HWC tensors]) batches in dataset order, `None` items dropped
+    (collate_fn's contract, utils.py:141-148).  Pillow releases the GIL while it inflates / decodes, so threads decode in parallel --
+    without the cost of starting worker processes (a fork-server worker imports torch: ~1 s each, 11 s for twelve on the MI355X
+    box's host, for a gallery the engine encodes in 1.6 s) and without pickling every decoded image through a pipe."""
+
+    def __init__(self, dataset, batch_size: int, threads: int, ahead: int = 3):
+        self.ds, self.bs, self.threads, self.ahead = dataset, batch_size, max(1, threads), ahead
+
+    def __len__(self):
+        return (len(self.ds) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        n = len(self.ds)
+        with ThreadPoolExecutor(max_workers=self.threads) as pool:
+            pending = deque()
+            starts = iter(range(0, n, self.bs))
+
+            def submit():
+                s = next(starts, None)
+                if s is not None:
+                    pending.append([pool.submit(self.ds.__getitem__, i) for i in range(s, min(s + self.bs, n))])
+
+            for _ in range(self.ahead):
+                submit()
+            while pending:
+                items = [f.result() for f in pending.popleft()]
+                submit()
+                yield _collate_ragged(items)
+
+
+def usable_cores() -> int:
+    """Host cores this process may use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, batch_size: Optional[int] = None, num_workers: int = 2,
                                 keep_raw=True, raw_dtype: Optional[torch.dtype] = None):
     """-> ((feats[N,32,256], raw), names[N])   (src/utils.py:46-77)
 
@@ -111,12 +156,20 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     gpu_tf = None
     if num_workers > 0 and not _pin(dataset):
         gpu_tf, dataset = _decode_only(dataset)
+        # image decoding is then the only host work and the slowest stage of a real gallery pass (one core decodes ~450 PNG files / s,
+        # the engine encodes ~1600 images / s): decode on a thread pool over the cores the host has (_ThreadLoader; the reference's
+        # loaders fork 2 processes: utils.py:54), at the batch the engine is benchmarked at
+        batch_size = batch_size or 128
+    batch_size = batch_size or 64                                    # utils.py:54
     # decode workers come from a fork SERVER (a small process started once): forking them from this process -- GPU context,
     # gigabytes of mapped memory -- cost ~24 s per loader on the MI355X box (tools/c2_e2e.py); SPRC_LOADER_CONTEXT overrides
     ctx = (os.environ.get("SPRC_LOADER_CONTEXT") or "forkserver") if num_workers > 0 else None
-    loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=gpu_tf is None and _pin(dataset),
-                        collate_fn=_collate_ragged if gpu_tf is not None else collate_fn, multiprocessing_context=ctx,
-                        persistent_workers=False)
+    if gpu_tf is not None and os.environ.get("SPRC_LOADER_THREADS", "1") != "0":
+        loader = _ThreadLoader(dataset, batch_size, threads=int(os.environ.get("SPRC_DECODE_THREADS") or max(2, min(12, usable_cores() - 2))))
+    else:
+        loader = DataLoader(dataset=dataset, batch_size=batch_size, num_workers=num_workers, pin_memory=gpu_tf is None and _pin(dataset),
+                            collate_fn=_collate_ragged if gpu_tf is not None else collate_fn, multiprocessing_context=ctx,
+                            persistent_workers=False)
     feats, raws, names = [], [], []
     split = getattr(dataset, "split", "")
     print(f"extracting {type(dataset).__name__} {split} index features")
@@ -124,10 +177,19 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     subset = keep_raw is not True
     wanted = set() if keep_raw in (False, None) else (set(keep_raw) if subset else None)
     rows: Dict[int, torch.Tensor] = {}
+    tf_stream = None
     for batch_names, images in tqdm(loader):
         if gpu_tf is not None:       # uint8 images go through the GPU transform; items a worker already transformed (modes the GPU
             from .data_utils import is_transformed      # path does not reproduce: palette, alpha, ...) are finished tensors
-            images = torch.stack([im.to(dev, non_blocking=True) if is_transformed(im) else gpu_tf(im) for im in images])
+            # on a side stream: a host-to-device copy from pageable memory blocks the host until everything queued before it on
+            # ITS stream is done -- on the compute stream that is the previous batch's 80 ms of encoding, and the next batch could
+            # not even be prepared meanwhile
+            if tf_stream is None:
+                tf_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(tf_stream):
+                images = torch.stack([im.to(dev, non_blocking=True) if is_transformed(im) else gpu_tf(im) for im in images])
+            torch.cuda.current_stream(dev).wait_stream(tf_stream)
+            images.record_stream(torch.cuda.current_stream(dev))
         images = images.to(dev, non_blocking=True)
         f, r = blip_model.extract_target_features(images, mode="mean")
         if raw_dtype is not None:

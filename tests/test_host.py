@@ -196,5 +196,16 @@ def test_query_loaders_stay_in_the_main_process_and_gallery_workers_only_decode(
     for im in (rgb.convert("P"), rgb.convert("RGBA"), rgb.convert("1")):
         out = dec(im)
         assert is_transformed(out) and torch.equal(out, HostTargetPad(1.25, 224)(im))
+    # the thread-pool decode loader: dataset order, ragged last batch, unreadable items dropped
+    class Items:
+        def __len__(self):
+            return 11
+
+        def __getitem__(self, i):
+            return None if i == 4 else (f"n{i}", torch.full((2 + i, 3, 3), i, dtype=torch.uint8))
+
+    got = list(H._ThreadLoader(Items(), batch_size=4, threads=3))
+    assert [b[0] for b in got] == [["n0", "n1", "n2", "n3"], ["n5", "n6", "n7"], ["n8", "n9", "n10"]]
+    assert all(int(t[0, 0, 0]) == int(n[1:]) for b in got for n, t in zip(*b)) and len(H._ThreadLoader(Items(), 4, 3)) == 3
     names, imgs = H._collate_ragged([("n0", torch.zeros(3, 4, 3, dtype=torch.uint8)), None, ("n1", torch.zeros(5, 2, 3, dtype=torch.uint8))])
     assert names == ["n0", "n1"] and [tuple(i.shape) for i in imgs] == [(3, 4, 3), (5, 2, 3)]

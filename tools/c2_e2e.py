@@ -70,6 +70,43 @@ def build(root: Path):
     torch.save({"Blip2QformerCirAlignPrompt": sd, "epoch": 0}, root / "ckpt.pt")
 
 
+def breakdown(root: Path):
+    """Where a real-data gallery pass spends its time: decode alone (the loader workers, no GPU work), the whole pass, and the engine
+    alone on resident tensors."""
+    from torch.utils.data import DataLoader
+    from sprc_amd import harness as H
+    from sprc_amd.blip_validate import _load, _preprocess
+    from sprc_amd.data_utils import CIRRDataset
+    model, _ = _load("blip2_cir_align_prompt", "pretrain", str(root / "ckpt.pt"), "fp16", None)
+    preprocess, workers = _preprocess(True, model.device)
+    ds = CIRRDataset("val", "classic", preprocess)
+    tf, dec = H._decode_only(ds)
+    nw = max(2, min(12, H.usable_cores() - 2))
+    t = time.perf_counter()
+    n = 0
+    for names, imgs in H._ThreadLoader(dec, 128, nw):
+        n += len(names)
+    t_dec = time.perf_counter() - t
+    H.extract_index_blip_features(ds, model, num_workers=workers, keep_raw=False)           # warm-up: engine build, workspaces
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    (feats, _), names = H.extract_index_blip_features(ds, model, num_workers=workers, keep_raw=False)
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t
+    x = torch.randn((128, 3, 224, 224), device=model.device)
+    for _ in range(2):
+        model.extract_target_features(x)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(10):
+        model.extract_target_features(x)
+    torch.cuda.synchronize()
+    t_enc = (time.perf_counter() - t) / 10
+    print(f"[c2_e2e breakdown] {H.usable_cores()} usable cores, {nw} decode threads: decode alone {n / t_dec:.0f} img/s "
+          f"({t_dec:.2f} s for {n} PNG files); whole gallery pass {len(names) / t_all:.0f} img/s ({t_all:.2f} s); engine alone on resident "
+          f"tensors {128 / t_enc:.0f} img/s", flush=True)
+
+
 def main():
     root = Path(os.environ.get("TMPDIR", "/tmp")) / "sprc_c2"
     t0 = time.perf_counter()
@@ -77,6 +114,8 @@ def main():
     print(f"dataset + checkpoint written in {time.perf_counter() - t0:.1f} s: {N_IMG} images, {NQ} queries under {root}", flush=True)
     os.environ["SPRC_DATA_ROOT"], os.environ["SPRC_BERT_VOCAB"] = str(root), str(root / "vocab.txt")
     from sprc_amd import blip_validate as bv
+    if os.environ.get("SPRC_C2_BREAKDOWN", "1") == "1":
+        breakdown(root)
     base = ["--dataset", "CIRR", "--model-path", str(root / "ckpt.pt")]
     out = {}
     for tag, extra in (("PIL transform in loader workers", []), ("GPU transform", ["--gpu-preprocess"]),
