@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=10, help="record per-launch HIP events on every Nth timed step, starting with the first (0 = never)")
     ap.add_argument("--vit-streams", type=int, default=1, help="2 = pipeline the two halves of a batch on two streams inside sprc_vit_forward (+4 %% images/s; per-kernel timings then overlap)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c5-slice"], help="c5-slice: ONE GPU's share of BASELINE config C5 (1 M-image gallery / 8 = "
+                    "a 125 000-image shard, 10 000 queries of which 1 250 are fused here): ViT-L encode steps of 128 images are timed, then the shard's fusion and "
+                    "ranking passes once; value = shard images / (encode time extrapolated over the shard + fusion + ranking).  Use with --backbone pretrain_vitL --dtype fp8")
     ap.add_argument("--qf-streams", type=int, default=2, help="2 = the gallery-side and the query-side Q-Former passes of a step run on two streams")
     ap.add_argument("--cpu-images", type=int, default=32, help="size of the bounded CPU-baseline sample (~15 s of CPU work on 16 cores)")
     return ap.parse_args()
@@ -137,6 +140,83 @@ def respawn(n: int) -> int:
     return subprocess.call(cmd)
 
 
+def c5_slice(a, dev, rank, world):
+    """One GPU's share of config C5 (see --workload): K timed encode steps, then the shard's 1250 fusions and the 10k x 125k ranking."""
+    from sprc_amd import engine as E
+    from sprc_amd import synth
+    from sprc_amd.config import get_config
+    if world != 1:
+        raise SystemExit("--workload c5-slice is a single-GPU line (the per-GPU share of the 8-GPU configuration)")
+    N_SHARD, NQ, NQ_LOCAL, QB = 125000, 10000, 1250, 2048
+    cfg = get_config(a.backbone)
+    sd = synth.make_state_dict(cfg, seed=0, device=str(dev))
+    g = torch.Generator(device=dev).manual_seed(99)
+    images = torch.randn((BATCH, 3, 224, 224), generator=g, device=dev)
+    if a.dtype == "fp8":
+        cal = E.Engine(cfg, sd, dev, dtype="bf16", max_batch=BATCH)
+        amax = cal.calibrate_fp8(images)
+        del cal
+        torch.cuda.empty_cache()
+        eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=250, fp8_amax=amax, fp8_margin=1.1)
+    else:
+        eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=250)
+    del sd
+    raw = torch.empty((BATCH, cfg.vit.tokens, cfg.vit.width), dtype=torch.float32, device=dev)
+    shard = torch.nn.functional.normalize(torch.randn((N_SHARD, 32, cfg.embed_dim), generator=g, device=dev), dim=-1).to(torch.bfloat16)
+    fusion_all = torch.nn.functional.normalize(torch.randn((NQ, cfg.embed_dim), generator=g, device=dev), dim=-1)
+    ids, mask, _ = synth.make_queries(NQ_LOCAL, BATCH, seed=5)
+    ids, mask = ids.to(dev), mask.to(dev)
+    ref_slot = (7919 * torch.arange(NQ_LOCAL, device=dev)) % BATCH
+    sim = torch.empty((QB, N_SHARD), dtype=torch.float32, device=dev)
+
+    def step(i):
+        eng.vit_forward(images, out=raw)
+        feats, f16 = eng.qformer_image(raw)
+        lo = (i * BATCH) % (N_SHARD - BATCH)
+        shard[lo:lo + BATCH].copy_(f16 if f16 is not None and f16.dtype == torch.bfloat16 else feats)
+
+    def fuse_and_rank():
+        for s in range(0, NQ_LOCAL, 250):
+            f, _ = eng.qformer_fuse(raw.index_select(0, ref_slot[s:s + 250]), ids[s:s + 250], mask[s:s + 250])
+            fusion_all[s:s + 250].copy_(f)
+        q16 = fusion_all.to(torch.bfloat16)
+        out = []
+        for s in range(0, NQ, QB):
+            n = min(QB, NQ - s)
+            E.sim_max(q16[s:s + n], shard, out=sim[:n])
+            out.append(E.topk(sim[:n], TOPK))
+        return out
+
+    for i in range(a.warmup):
+        step(i)
+    fuse_and_rank()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / a.steps
+    t0 = time.perf_counter()
+    fuse_and_rank()
+    torch.cuda.synchronize()
+    t_fr = time.perf_counter() - t0
+    total = N_SHARD / BATCH * t_step + t_fr
+    peak = MFMA_FP8_PEAK_TFLOPS if a.dtype == "fp8" else MFMA_BF16_PEAK_TFLOPS
+    enc_tflop = BATCH * GFLOP_PER_IMAGE[a.backbone] * 1e-3
+    out = {"metric": "gallery images encoded+ranked/sec", "value": round(N_SHARD / total, 2), "unit": "images/s", "n_gpus": 1, "steps": a.steps,
+           "warmup": a.warmup, "ms_per_step": round(t_step * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": f"C5 slice (one GPU of eight): {N_SHARD}-image shard of a 1 M gallery, {NQ} queries ranked, {NQ_LOCAL} fused here; "
+                                  f"{'ViT-L' if a.backbone == 'pretrain_vitL' else 'ViT-g'} {a.dtype} encode timed over {a.steps} steps of {BATCH} images and "
+                                  f"EXTRAPOLATED over the shard ({N_SHARD / BATCH * t_step:.1f} s), + the shard's fusion and bf16 ranking passes measured once "
+                                  f"({t_fr * 1e3:.0f} ms)", "backbone": a.backbone, "batch": BATCH, "shard": N_SHARD, "queries": NQ,
+                      "fuse_rank_ms": round(t_fr * 1e3, 1), "rank_dtype": "bf16", "topk": TOPK},
+           "roofline": {"bound": "mfma", "kernel": GEMM_KERNELS.get(a.dtype, a.dtype), "achieved": round(enc_tflop / t_step, 1), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(enc_tflop / t_step / peak, 4), "traffic": None,
+                        "note": "whole encode step (algorithmic flops of 128 images / step time), not a per-kernel figure"}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
     if a.gpus < 1:
@@ -175,6 +255,8 @@ def main():
     from sprc_amd.dist import ShardedRanker, owner_of, shard_bounds
 
     lib = L.load()
+    if a.workload == "c5-slice":
+        return c5_slice(a, dev, rank, world)
     cfg = get_config(a.backbone)
     sd = synth.make_state_dict(cfg, seed=0, device=str(dev))      # random-init weights of the named architecture
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -103,7 +103,8 @@ def test_layernorm_fp8_copy_and_absmax():
 def test_fp8_vit_in_the_pipeline(golden_dir, name):
     """fp8 ViT (qkv / fc1 / fc2 on e4m3 operands; attention, proj, Q-Former bf16; residual / LN / softmax fp32) against the
     reference goldens.  Scales are calibrated on the golden's own images (static per-tensor activation scales).  Measured
-    on MI355X: max |dsim| 2e-3 .. 6e-3 (bf16: 4e-4 .. 1e-3) -- e4m3 has 3 mantissa bits; the bound asserted is 1.5e-2."""
+    on MI355X (round 3): max |dsim| 5.6e-4 .. 1.9e-3 over the four goldens (bf16: 8e-4 .. 1e-3) -- e4m3 has 3 mantissa bits; the bound
+    asserted is the largest measured value + 50 %."""
     g = np.load(golden_dir / name, allow_pickle=False)
     cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
     sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
@@ -124,6 +125,6 @@ def test_fp8_vit_in_the_pipeline(golden_dir, name):
     rows = g["rows"].tolist()
     print(f"\n[{name} fp8] max|dsim|={dsim:.2e} min cos(feats)={cos:.6f} max|draw| vs reference={np.abs(raw.cpu().numpy()[:, rows] - g['raw']).max():.2e} "
           f"(bf16 engine: {np.abs(raw16.cpu().numpy()[:, rows] - g['raw']).max():.2e})")
-    assert torch.isfinite(raw).all() and cos > 0.99 and dsim < 1.5e-2
+    assert torch.isfinite(raw).all() and cos > 0.99 and dsim < 3e-3
     with pytest.raises(ValueError):
         E.Engine(cfg, sd, DEV, dtype="fp8")                                  # no calibration data
