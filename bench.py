@@ -72,6 +72,8 @@ def parse():
                     "a 125 000-image shard, 10 000 queries of which 1 250 are fused here): ViT-L encode steps of 128 images are timed, then the shard's fusion and "
                     "ranking passes once; value = shard images / (encode time extrapolated over the shard + fusion + ranking).  Use with --backbone pretrain_vitL --dtype fp8")
     ap.add_argument("--qf-streams", type=int, default=2, help="2 = the gallery-side and the query-side Q-Former passes of a step run on two streams")
+    ap.add_argument("--pipeline", type=int, default=1, help="1 = batch i's Q-Former passes and ranking overlap batch i+1's ViT (side streams, raw embeddings "
+                    "double-buffered); instrumented steps (--prof-every) stay serialised")
     ap.add_argument("--cpu-images", type=int, default=32, help="size of the bounded CPU-baseline sample (~15 s of CPU work on 16 cores)")
     return ap.parse_args()
 
@@ -270,7 +272,8 @@ def main():
         torch.cuda.empty_cache()
         eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=max(BATCH, Q_PER_STEP), fp8_amax=amax, fp8_margin=1.1)
     else:
-        eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=max(BATCH, Q_PER_STEP))
+        eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=max(BATCH, Q_PER_STEP),
+                       qformer_x3=(0 if os.environ.get("SPRC_X3_OFF") else None))       # SPRC_X3_OFF=1: A/B line without the split-precision Q-Former
     del sd
     torch.cuda.empty_cache()
     ids, mask, _ = synth.make_queries(Q_PER_STEP, GALLERY, seed=1 + rank)
@@ -289,6 +292,36 @@ def main():
     # passes are independent until the ranking: they run on two streams (--qf-streams 1 serialises them for A/B runs).
     side = torch.cuda.Stream(device=dev) if a.qf_streams >= 2 else None
     main = torch.cuda.current_stream(dev)
+    # --pipeline 1: the Q-Former passes + ranking of batch i run on side streams WHILE the ViT of batch i+1 runs on the main stream (raw
+    # embeddings double-buffered): the ViT's GEMMs own every CU while they run, but their partial last rounds, the small remainder
+    # launches and the bandwidth-bound LayerNorms leave CUs idle that the Q-Former's small launches can take.  Steps whose launches
+    # are timed with HIP events (--prof-every) run serialised, so per-kernel durations stay those of a kernel that has the chip.
+    pipe = a.pipeline and side is not None
+    s_img, s_fuse = (side, torch.cuda.Stream(device=dev)) if pipe else (None, None)
+    raws = [raw, torch.empty_like(raw)] if pipe else [raw]
+    done = [torch.cuda.Event(), torch.cuda.Event()] if pipe else None
+
+    def step_pipelined(i: int):
+        buf = raws[i % 2]
+        main.wait_event(done[i % 2])                                              # batch i-2's Q-Former passes have read this buffer
+        eng.vit_forward(images, out=buf)
+        lo = (i * BATCH) % (GALLERY - BATCH)
+        s_img.wait_stream(main)
+        s_fuse.wait_stream(main)
+        with torch.cuda.stream(s_img):
+            feats, _ = eng.qformer_image(buf)
+            gallery[lo:lo + BATCH].copy_(feats)
+        with torch.cuda.stream(s_fuse):
+            fusion, _ = eng.qformer_fuse(buf.index_select(0, ref_slot), ids, mask)
+            s_fuse.wait_stream(s_img)                                             # the ranking reads the gallery slice of this batch
+            out = ranker.rank(fusion, TOPK)
+            done[i % 2].record(s_fuse)
+        return out
+
+    def drain():
+        if pipe:
+            main.wait_stream(s_img)
+            main.wait_stream(s_fuse)
 
     def step(i: int):
         eng.vit_forward(images, out=raw)                                          # R3/R4
@@ -313,7 +346,8 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        step(i)
+        (step_pipelined if pipe else step)(i)
+    drain()
     barrier()
     # Per-launch HIP events cost two stream markers per launch (~7 us of pipeline bubble: 4.5 ms on a 100-ms step when every
     # launch is recorded), so they are recorded on every `prof_every`-th step of the timed region only; `value` is the
@@ -323,11 +357,14 @@ def main():
     for i in range(a.steps):
         rec = a.prof_every > 0 and i % a.prof_every == 0
         if rec:
+            drain()
             lib.sprc_prof_enable(1 if n_prof == 0 else 2)
             n_prof += 1
-        step(a.warmup + i)
-        if rec:
+            step(a.warmup + i)                                                    # instrumented steps: serialised (see `pipe`)
             lib.sprc_prof_enable(0)
+        else:
+            (step_pipelined if pipe else step)(a.warmup + i)
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     n_prof = max(n_prof, 1)
@@ -359,13 +396,13 @@ def main():
         # committed rocprofv3 passes over this same command (tools/profile_bench.sh -> profiles/r01_traffic.json)
         # -- and only when that profile was taken on THIS build (it records the hash of the kernel sources): otherwise null
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if a.dtype == "bf16" and a.backbone == "pretrain" and a.vit_streams == 1 and os.path.exists(tj) and pe.launches:
+        tj = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if a.dtype == "fp16" and a.backbone == "pretrain" and a.vit_streams == 1 and os.path.exists(tj) and pe.launches and not os.environ.get("SPRC_X3_OFF"):
             with open(tj) as f:
                 tr = json.load(f)
             if tr.get("kernel_source_sha") == kernel_source_sha():
                 traffic = round(tr["gemm_bytes_per_step"]["total"] / (pe.launches / n_prof), 1)
-                traffic_src = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only "
+                traffic_src = ("profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only "
                                "passes over this command on this build: kernel_source_sha %s)" % tr["kernel_source_sha"][:12])
         # whole-step utilisation: ALGORITHMIC flops of one step over the step time, against the dtype's peak
         step_tflop = (BATCH * GFLOP_PER_IMAGE[a.backbone] + Q_PER_STEP * GFLOP_PER_QUERY[a.backbone]) * 1e-3 \
@@ -383,7 +420,7 @@ def main():
                                    f"{'ViT-g' if a.backbone == 'pretrain' else 'ViT-L'} {a.dtype}, batch {BATCH}; step = encode {BATCH} images + "
                                    f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
-                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_streams": a.qf_streams,
+                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_streams": a.qf_streams, "pipeline": int(bool(a.pipeline)),
                        "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and backend == "nccl" else None),
                        "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNELS[a.dtype], "achieved": round(ach, 1), "peak": peak,

@@ -658,6 +658,7 @@ static int launch_stream(const AttnParams& p, hipStream_t st) {
 }  // namespace sprc
 
 namespace sprc {
+static bool Tk_all_le64(const AttnParams& p) { return p.Tk <= 64; }
 // 16-bit engines (F16: fp16 operands, else bf16): kernel choice by shape
 template <bool F16>
 static int attention16(const sprc_attention_args* a, const AttnParams& p, bool two, hipStream_t st) {
@@ -685,6 +686,13 @@ static int attention16(const sprc_attention_args* a, const AttnParams& p, bool t
         if (a->head_dim <= 64) return launch_bf16<64, 9, F16>(p, st);
         return launch_bf16<96, 9, F16>(p, st);
     }
+    // small query axes (the Q-Former: 32 or 64 query rows = one or two 32-row tiles): SPRC_ATTN_SMALL_NW waves per workgroup
+    static const int small_nw = [] { const char* e = getenv("SPRC_ATTN_SMALL_NW"); return e ? atoi(e) : 4; }();
+    // measured (tools/qf_attn_bench.py, 233 x 12 heads): self-attention over 64 keys 40.9 us with four waves per workgroup, 28.5 with
+    // two (one per query tile: twice the workgroups per CU); cross-attention over 257 keys 84.5 / 106.8 / 142.5 us with 4 / 2 / 1
+    // waves (there the extra waves carry the K / V staging) -> two waves for short key axes, four otherwise
+    if (a->head_dim <= 64 && small && (small_nw == 2 || (small_nw == 4 && Tk_all_le64(p)))) return launch_bf16<64, 2, F16>(p, st);
+    if (a->head_dim <= 64 && small && small_nw == 1) return launch_bf16<64, 1, F16>(p, st);
     if (a->head_dim <= 64) return small ? launch_bf16<64, 4, F16>(p, st) : launch_bf16<64, 8, F16>(p, st);
     return small ? launch_bf16<96, 4, F16>(p, st) : launch_bf16<96, 8, F16>(p, st);
 }

@@ -978,6 +978,24 @@ static void optin_lds(K kern, int bytes, bool (&done)[MAX_DEVICES]) {
     }
 }
 
+// one helper stream + fork / join events per device (streams and events belong to the device they were created on)
+struct SideStream { hipStream_t st; hipEvent_t fork, join; };
+static SideStream* side_stream() {
+    static const int on = env_int("SPRC_GEMM_SIDE", 0);      // off: measured 89.7 -> 93.0 ms per bench step WITH it (see the call site)
+    if (!on) return nullptr;
+    static SideStream pool[MAX_DEVICES] = {};
+    static int state[MAX_DEVICES] = {0};                // 0 = not created yet, 1 = ready, -1 = creation failed
+    const int dev = current_device();
+    if (state[dev] == 0) {
+        SideStream& h = pool[dev];
+        const bool ok = hipStreamCreateWithFlags(&h.st, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&h.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&h.join, hipEventDisableTiming) == hipSuccess;
+        state[dev] = ok ? 1 : -1;
+    }
+    return state[dev] == 1 ? &pool[dev] : nullptr;
+}
+
 template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT, int NS = 2>
 static int launch_cfg(GemmParams p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = NS * (BM + BN) * 128;
@@ -1084,8 +1102,23 @@ static int launch(const GemmParams& p, hipStream_t st) {
                 pt.A = p.A + (int64_t)Mm * p.lda_b;
                 pt.C = reinterpret_cast<char*>(p.C) + (int64_t)Mm * p.ldc * (MAX32 ? 4 : (int64_t)sizeof(OutT));
                 if (p.resid != nullptr) pt.resid = p.resid + (int64_t)Mm * p.ldr;
+                // SPRC_GEMM_SIDE=1 (A/B switch, OFF by default): the remainder rows (disjoint from the main launch's) go to a library-owned
+                // side stream, forked before and joined after the main launch, so that their handful of latency-bound workgroups
+                // (11-16 us per launch, 1.8 ms of a bench step when run behind the main kernel) could start as soon as CUs of the main
+                // kernel's last round fall idle.  Measured on MI355X: the step got SLOWER, 89.7 -> 93.0 ms (same box, twice) -- the two
+                // extra event pairs per product and the remainder workgroups taking CUs from the main kernel's first round cost more
+                // than the 1.8 ms they could hide.
+                SideStream* ss = side_stream();
+                hipStream_t sr = st;
+                if (ss != nullptr) {
+                    (void)hipEventRecord(ss->fork, st);
+                    (void)hipStreamWaitEvent(ss->st, ss->fork, 0);
+                    sr = ss->st;
+                }
                 const int rc = launch_anti<T, OutT, ACT, MAX32>(pm, st);
                 if (rc != SPRC_OK) return rc;
+                const int rr = [&]() -> int {
+                hipStream_t st = sr;                 // (shadows the caller's stream inside the remainder launches)
                 // remainder rows: a long reduction on a handful of workgroups is latency-bound (11 WGs x 96 K-tiles = 77 us
                 // for the ViT fc2) -> split K over 8 workgroups per tile into caller scratch and reduce in a fixed order
                 constexpr int S = 8;
@@ -1111,6 +1144,12 @@ static int launch(const GemmParams& p, hipStream_t st) {
                         return ring ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4>(pt, st) : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(pt, st);
                 }
                 return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(pt, st);
+                }();
+                if (ss != nullptr) {
+                    (void)hipEventRecord(ss->join, sr);
+                    (void)hipStreamWaitEvent(st, ss->join, 0);
+                }
+                return rr;
             }
             cfg = cB <= cA ? 4 : 2;
             // a 128x128 grid that cannot even give every CU one workgroup is latency-bound (12-48 K-tiles on a fraction of the

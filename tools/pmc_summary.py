@@ -31,11 +31,18 @@ def summarise(match):
         d["mean_duration_us"] = sum(dur) / len(dur) / 1e3
         d["total_duration_ms"] = sum(dur) / 1e6
         d["dispatches_timed"] = len(dur)
-    if m("GRBM_GUI_ACTIVE") and dur:
-        d["effective_clock_GHz"] = m("GRBM_GUI_ACTIVE") / 8 / (sum(dur) / len(dur))      # the counter is summed over the 8 XCDs
+    # GRBM_GUI_ACTIVE (summed over the 8 XCDs) spans the counter-collection window of a dispatch, which is longer than the kernel:
+    # "GRBM_GUI_ACTIVE / 8 / kernel time" came out at 3.3 GHz for 12-us launches on a 2.4-GHz part.  The ratio
+    # is only reported for dispatches long enough for the window's edges not to matter (>= 150 us), and flagged as an upper bound.
+    mean_us = sum(dur) / len(dur) / 1e3 if dur else 0.0
+    if m("GRBM_GUI_ACTIVE") and dur and mean_us >= 150.0:
+        d["effective_clock_GHz_upper_bound"] = m("GRBM_GUI_ACTIVE") / 8 / (sum(dur) / len(dur))
+    if m("SQ_VALU_MFMA_BUSY_CYCLES") and dur:
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA), summed over the chip's 1024 SIMDs.  Against the kernel's
+        # WALL time at the part's maximum clock: the matrix pipe's share of the time the launch took, whatever clock it ran at
+        d["mfma_busy_frac_of_wall_at_2p4GHz"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (sum(dur) / len(dur) * 2.4)
     if m("SQ_VALU_MFMA_BUSY_CYCLES") and m("GRBM_GUI_ACTIVE"):
-        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per 32x32x16 MFMA), summed over the chip's 1024 SIMDs
-        d["mfma_busy_frac"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (m("GRBM_GUI_ACTIVE") / 8)
+        d["mfma_busy_frac"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (m("GRBM_GUI_ACTIVE") / 8)       # of the counter window's cycles
     if m("SQ_LDS_BANK_CONFLICT") is not None and m("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_frac"] = m("SQ_LDS_BANK_CONFLICT") / m("SQ_LDS_IDX_ACTIVE")
     if m("SQ_WAVE_CYCLES"):

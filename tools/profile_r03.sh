@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-3 measurement artifacts, all from ONE box and ONE build (run through gpurun; copy gpurun_out/r03/* to profiles/r03_*):
+#   bench_n1.json             un-profiled `python bench.py --steps 20 --warmup 5` line (headline: ViT-g fp16 + split-precision Q-Former)
+#   bench_n1_bf16.json, bench_n1_fp16_single.json   the same step in bf16 and in fp16 without the split-precision Q-Former (same box)
+#   bench_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary of `bench.py --steps 3 --warmup 1 --no-cpu-baseline`
+#   traffic.json              FETCH_SIZE / WRITE_SIZE counter passes over the same command (GEMM bytes per step) + kernel_source_sha
+#   pmc.json                  SQ / GRBM / TCC counter passes summarised per kernel class
+#   bench_vitL_{bf16,fp16,fp8}.json   config C5's backbone on the C2-shaped step;  bench_c5_slice_fp8.json   one GPU's share of C5
+#   bench_n2_one_gpu.json     `bench.py --gpus 2` on this 1-GPU box (two ranks sharing the GPU, gloo): plumbing check only
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd $R
+bash tools/profile_bench.sh r03/pb > $O/profile_bench.log 2>&1
+cp $O/pb/kernel_stats.csv $O/bench_kernel_stats.csv; cp $O/pb/traffic.json $O/traffic.json
+cp $O/traffic.json profiles/r03_traffic.json        # bench.py reads roofline.traffic from here (same box, same kernel sources)
+python bench.py --steps 20 --warmup 5 > $O/bench_n1.log 2>&1; tail -1 $O/bench_n1.log > $O/bench_n1.json
+python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_n1_bf16.json
+SPRC_X3_OFF=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_n1_fp16_single.json
+bash tools/pmc_kernel.sh r03/pmc "gemm_anti=gemm_anti_kernel,gemm_128=gemm_kernel,attention=attn_,layernorm=layernorm_kernel" -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --qf-streams 1 > $O/pmc.log 2>&1
+cp $O/pmc/summary.json $O/pmc.json
+for dt in bf16 fp16 fp8; do python bench.py --backbone pretrain_vitL --dtype $dt --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_vitL_$dt.json; done
+python bench.py --workload c5-slice --backbone pretrain_vitL --dtype fp8 --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/bench_c5_slice_fp8.json
+python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_n2_one_gpu.json
+bash tools/trace_top.sh > $O/trace_top.txt 2>&1
+rm -rf $O/pb/kt $O/pb/pmc_* $O/pmc/p? $O/pmc/kt $R/gpurun_out/trace_top/kt
+head -c 400 $O/bench_n1.json; echo; tail -40 $O/pmc.log
