@@ -295,7 +295,8 @@ def main():
     # --pipeline 1: the Q-Former passes + ranking of batch i run on side streams WHILE the ViT of batch i+1 runs on the main stream (raw
     # embeddings double-buffered): the ViT's GEMMs own every CU while they run, but their partial last rounds, the small remainder
     # launches and the bandwidth-bound LayerNorms leave CUs idle that the Q-Former's small launches can take.  Steps whose launches
-    # are timed with HIP events (--prof-every) run serialised, so per-kernel durations stay those of a kernel that has the chip.
+    # are timed with HIP events (--prof-every) run on ONE stream, so per-kernel durations stay those of a kernel that has the chip
+    # (and agree with a `rocprofv3 --kernel-trace` of `--pipeline 0 --qf-streams 1`, profiles/).
     pipe = a.pipeline and side is not None
     s_img, s_fuse = (side, torch.cuda.Stream(device=dev)) if pipe else (None, None)
     raws = [raw, torch.empty_like(raw)] if pipe else [raw]
@@ -323,10 +324,10 @@ def main():
             main.wait_stream(s_img)
             main.wait_stream(s_fuse)
 
-    def step(i: int):
+    def step(i: int, serial: bool = False):
         eng.vit_forward(images, out=raw)                                          # R3/R4
         lo = (i * BATCH) % (GALLERY - BATCH)
-        if side is not None:
+        if side is not None and not serial:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 feats, _ = eng.qformer_image(raw)                                 # R5(i) + vision_proj
@@ -360,7 +361,7 @@ def main():
             drain()
             lib.sprc_prof_enable(1 if n_prof == 0 else 2)
             n_prof += 1
-            step(a.warmup + i)                                                    # instrumented steps: serialised (see `pipe`)
+            step(a.warmup + i, serial=True)                                       # instrumented steps: ONE stream (see `pipe`)
             lib.sprc_prof_enable(0)
         else:
             (step_pipelined if pipe else step)(a.warmup + i)

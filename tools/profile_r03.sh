@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03
 mkdir -p $O
 cd $R
-bash tools/profile_bench.sh r03/pb > $O/profile_bench.log 2>&1
+bash tools/profile_bench.sh r03/pb --pipeline 0 --qf-streams 1 > $O/profile_bench.log 2>&1      # one stream: a kernel's duration is its own
 cp $O/pb/kernel_stats.csv $O/bench_kernel_stats.csv; cp $O/pb/traffic.json $O/traffic.json
 cp $O/traffic.json profiles/r03_traffic.json        # bench.py reads roofline.traffic from here (same box, same kernel sources)
 python bench.py --steps 20 --warmup 5 > $O/bench_n1.log 2>&1; tail -1 $O/bench_n1.log > $O/bench_n1.json
@@ -22,6 +22,6 @@ cp $O/pmc/summary.json $O/pmc.json
 for dt in bf16 fp16 fp8; do python bench.py --backbone pretrain_vitL --dtype $dt --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_vitL_$dt.json; done
 python bench.py --workload c5-slice --backbone pretrain_vitL --dtype fp8 --steps 20 --warmup 3 2>/dev/null | tail -1 > $O/bench_c5_slice_fp8.json
 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/bench_n2_one_gpu.json
-bash tools/trace_top.sh > $O/trace_top.txt 2>&1
+bash tools/trace_top.sh --pipeline 0 --qf-streams 1 > $O/trace_top.txt 2>&1
 rm -rf $O/pb/kt $O/pb/pmc_* $O/pmc/p? $O/pmc/kt $R/gpurun_out/trace_top/kt
 head -c 400 $O/bench_n1.json; echo; tail -40 $O/pmc.log
