@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32", "fp8"], help="fp16: fp16 MFMA operands (the reference's GPU autocast precision; the bf16 rate); fp8: bf16 engine whose ViT qkv / fc1 / fc2 GEMMs run on e4m3fn operands (BASELINE config C5)")
+    ap.add_argument("--fp8-base", default="bf16", choices=["bf16", "fp16"], help="--dtype fp8: the 16-bit dtype of everything but the fp8 GEMMs (fp16: with the split-precision Q-Former)")
+    ap.add_argument("--fp8-layers", default="all", choices=["all", "mlp"], help="--dtype fp8: which ViT GEMMs take e4m3 operands: qkv + fc1 + fc2, or fc1 + fc2 only")
     ap.add_argument("--backbone", default="pretrain", choices=["pretrain", "pretrain_vitL"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-every", type=int, default=10, help="record per-launch HIP events on every Nth timed step, starting with the first (0 = never)")
@@ -155,11 +157,11 @@ def c5_slice(a, dev, rank, world):
     g = torch.Generator(device=dev).manual_seed(99)
     images = torch.randn((BATCH, 3, 224, 224), generator=g, device=dev)
     if a.dtype == "fp8":
-        cal = E.Engine(cfg, sd, dev, dtype="bf16", max_batch=BATCH)
+        cal = E.Engine(cfg, sd, dev, dtype=a.fp8_base, max_batch=BATCH, qformer_x3=0)
         amax = cal.calibrate_fp8(images)
         del cal
         torch.cuda.empty_cache()
-        eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=250, fp8_amax=amax, fp8_margin=1.1)
+        eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=250, fp8_amax=amax, fp8_margin=1.1, fp8_base=a.fp8_base, fp8_layers=a.fp8_layers)
     else:
         eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=250)
     del sd
@@ -264,13 +266,14 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn((BATCH, 3, 224, 224), generator=g, device=dev)           # synthetic, already "normalised"
     if a.dtype == "fp8":
-        # static activation scales: one calibration pass of the bf16 engine over a batch of the synthetic images
+        # static activation scales: one calibration pass of the 16-bit engine over a batch of the synthetic images
         # (outside the timed region, like packing the weights); 10 % head-room over the observed maxima
-        cal = E.Engine(cfg, sd, dev, dtype="bf16", max_batch=BATCH)
+        cal = E.Engine(cfg, sd, dev, dtype=a.fp8_base, max_batch=BATCH, qformer_x3=0)
         amax = cal.calibrate_fp8(images)
         del cal
         torch.cuda.empty_cache()
-        eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=max(BATCH, Q_PER_STEP), fp8_amax=amax, fp8_margin=1.1)
+        eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=max(BATCH, Q_PER_STEP), fp8_amax=amax, fp8_margin=1.1,
+                       fp8_base=a.fp8_base, fp8_layers=a.fp8_layers)
     else:
         eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=max(BATCH, Q_PER_STEP),
                        qformer_x3=(0 if os.environ.get("SPRC_X3_OFF") else None))       # SPRC_X3_OFF=1: A/B line without the split-precision Q-Former
@@ -412,7 +415,7 @@ def main():
                              "autocast (blip2.py:36-44), Q-Former at split-precision (hi + lo fp16 operands, masks image %d / query %d) as the "
                              "reference keeps it in fp32 (align_prompt.py:366-368)" % (eng.x3_image, eng.x3_fuse),
                      "bf16": "bf16 MFMA operands, fp32 accumulate / residual stream / LayerNorm / softmax",
-                     "fp8": "bf16 engine, ViT qkv / fc1 / fc2 on e4m3 MX MFMA", "fp32": "exact fp32 MFMA"}[a.dtype]
+                     "fp8": f"{a.fp8_base} engine, ViT {'qkv / ' if a.fp8_layers == 'all' else ''}fc1 / fc2 on e4m3 MX MFMA", "fp32": "exact fp32 MFMA"}[a.dtype]
         out = {
             "metric": "gallery images encoded+ranked/sec", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),

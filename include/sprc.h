@@ -77,6 +77,8 @@ int sprc_prof_collect(sprc_prof_entry* out /* [SPRC_K_COUNT] */);
 
 /* amax[0] = max(amax[0], max |x|) over n bf16 values (device float, caller-initialised): fp8 scale calibration. */
 int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s);
+/* the same over n 16-bit values of `dtype` (SPRC_BF16 or SPRC_F16) */
+int sprc_absmax_16(const void* x, size_t n, int32_t dtype, float* amax, sprc_stream s);
 
 /* fp32 -> bf16 (round-to-nearest-even) weight/feature packing. */
 int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s);
@@ -91,7 +93,7 @@ int sprc_cast_f32_to_x3(const float* src, void* dst, int64_t rows, int32_t cols,
  * K % 64 == 0 (bf16, fp16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (16-bit) / 4 (f32) elements.
  * dtype SPRC_F16: outputs fp16, f32 or SPRC_F16X3 (ldc >= 3 N, N % 4 == 0; no residual, no max32), every activation.
  * out_dtype SPRC_F16 with bf16 operands: no activation / residual / max32 (see sprc_layernorm_args.add16).
- * dtype SPRC_FP8: K % 128 == 0; outputs bf16 / f32 (plain epilogue, residual allowed) or fp8 (any activation).
+ * dtype SPRC_FP8: K % 128 == 0; outputs bf16 / fp16 / f32 (plain epilogue, residual allowed) or fp8 (any activation).
  *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
  * max32 != 0: "similarity" epilogue -- rows of A are query vectors, rows of W are gallery tokens (32 per
  * image); out[m*ldc + n/32] = max over the 32 W-rows of image n/32 (align_prompt.py:353-358). */
@@ -228,13 +230,15 @@ int sprc_rank_of(const float* sim, int64_t ld, const int32_t* listed, int32_t nq
 
 enum { SPRC_X3_QKV = 1, SPRC_X3_ATTN_OUT = 2, SPRC_X3_CROSS_Q = 4, SPRC_X3_CROSS_OUT = 8, SPRC_X3_FFN_IN = 16, SPRC_X3_FFN_OUT = 32,
        SPRC_X3_CKV = 64, SPRC_X3_HEADS = 128, SPRC_X3_ALL = 255 };      /* layer kinds of sprc_qformer_model.x3 */
+enum { SPRC_FP8_ALL = 1, SPRC_FP8_MLP = 2 };                          /* sprc_vit_model.fp8 */
 typedef struct { const void* w; const float* b; } sprc_linear;   /* w: [out,in(padded)] compute dtype */
 
 typedef struct {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     sprc_linear qkv, proj, fc1, fc2;            /* qkv bias: [q_bias, 0, v_bias] (eva_vit.py:120-122) */
     /* fp8 ViT (sprc_vit_model.fp8 != 0): qkv / fc1 / fc2 weights are e4m3fn with per-output-channel scales, their inputs are
-     * quantised with the static per-tensor scales below (a = s * a_q); proj stays bf16 (its input is the attention output) */
+     * quantised with the static per-tensor scales below (a = s * a_q); proj stays 16-bit (its input is the attention output);
+     * with fp8 == SPRC_FP8_MLP qkv is a 16-bit linear like proj */
     const float *qkv_ws, *fc1_ws, *fc2_ws;      /* [3*width], [mlp], [width] fp32 */
     float s_ln1, s_ln2, s_mlp;                  /* activation scales of the qkv / fc1 / fc2 inputs */
 } sprc_vit_layer;
@@ -246,8 +250,10 @@ typedef struct {
     const float *cls, *pos;                     /* [width], [tokens,width] */
     const float *ln_pre_w, *ln_pre_b, *ln_vision_w, *ln_vision_b;
     const sprc_vit_layer* layers;               /* host array [depth] */
-    int32_t fp8;                                /* 1: dtype is SPRC_BF16 and the three big GEMMs of every block run on fp8 operands */
-    float* calib_amax;                          /* optional device array [depth*3] (bf16 model only): running max |x| of the qkv / fc1 /
+    int32_t fp8;                                /* dtype SPRC_BF16 or SPRC_F16 (everything else of the model computes in it) and
+                                                 * SPRC_FP8_ALL (1): qkv, fc1 and fc2 of every block run on fp8 operands;
+                                                 * SPRC_FP8_MLP (2): fc1 and fc2 only */
+    float* calib_amax;                          /* optional device array [depth*3] (16-bit model, fp8 == 0): running max |x| of the qkv / fc1 /
                                                  * fc2 inputs, updated by sprc_vit_forward -- the calibration pass of the fp8 scales */
     float* pre_ln_out;                          /* optional device array [B, tokens, width] fp32: receives the INPUT of ln_vision (the ViT's last
                                                  * residual stream) -- what the training step needs for ln_vision's gradient (blip2.py:81) */

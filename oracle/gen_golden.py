@@ -213,12 +213,12 @@ def planted_targets(sim: np.ndarray, ref: np.ndarray, seed: int = 0, margin: flo
     return tgt, groups
 
 
-def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int = 4, seed: int = 0):
+def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int = 4, seed: int = 0, model_type: str = "pretrain"):
     """Planted-structure ordering fixture: depth-4 ViT-g + the full Q-Former run by the REFERENCE on 160 gallery images
     and 72 composed queries; scores spread over > 1.0; targets at planned ranks; the reference's own
     compute_cirr_val_metrics / compute_fiq_val_metrics / generate_cirr_test_dicts evaluated on its own scores."""
     from torch.utils.data import Dataset
-    cfg = get_config("pretrain", vit_depth=vit_depth)
+    cfg = get_config(model_type, vit_depth=vit_depth)
     sd = synth.make_state_dict(cfg, seed=seed, planted=True)
     model = ref_import.build_reference_model(cfg, sd)
     images = synth.make_images(n_img, seed=seed, planted=True)
@@ -276,7 +276,7 @@ def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int =
     s_sorted = np.sort(sim, axis=1)
     gaps = np.diff(s_sorted, axis=1)
     np.savez_compressed(
-        out, model_type="pretrain", vit_depth=cfg.vit.depth, seed=seed, n_img=n_img, n_q=n_q,
+        out, model_type=model_type, vit_depth=cfg.vit.depth, seed=seed, n_img=n_img, n_q=n_q,
         image_probe=_np(images[:4, :, 0, :4]), input_ids=ids.numpy(), attention_mask=mask.numpy(), ref_index=refn,
         tgt_index=tgt, groups=groups, sim=sim, fusion=fusion, feats_head=_np(feats[:4]), raw_head=_np(raw[:2][:, ROWS]),
         cirr=np.array(cirr, dtype=np.float64), fiq=np.array(fiq, dtype=np.float64),
@@ -428,6 +428,8 @@ def main():
         planted_goldens(GOLD / "planted_eva.npz")
     if a.full and want("planted_full"):      # full depth (39 blocks), 96 gallery images x 48 queries: the dtype-parity case
         planted_goldens(GOLD / "planted_full_eva.npz", n_img=96, n_q=48, vit_depth=None)
+    if a.full and want("planted_clip"):      # the same on config C5's backbone (CLIP ViT-L, 24 blocks): the fp8 path's structured case
+        planted_goldens(GOLD / "planted_full_clip.npz", n_img=96, n_q=48, vit_depth=None, model_type="pretrain_vitL")
     if a.full and want("full_eva"):
         model_goldens("pretrain", None, n_img=2, n_q=3, out=GOLD / "full_eva.npz")
     if a.full and want("full_clip"):

@@ -16,8 +16,9 @@ SPRC_F16X3 = 4                                        # storage layout of split-
 SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: IEEE half (compute dtype since ABI 3); FP8: OCP e4m3fn operands
 ABI_VERSION = 3
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
+FP8_ALL, FP8_MLP = 1, 2                               # sprc_vit_model.fp8: qkv + fc1 + fc2, or fc1 + fc2 only, on e4m3fn operands
 DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16, "fp16": SPRC_F16, "f16": SPRC_F16,
-          "fp8": SPRC_BF16}     # "fp8" engine: bf16 model + fp8 ViT GEMMs
+          "fp8": SPRC_BF16}     # "fp8" engine: a 16-bit model (Engine(fp8_base=...): bf16 by default) + fp8 ViT GEMMs
 
 
 def is16(dt: int) -> bool:
@@ -117,6 +118,7 @@ SIGNATURES = {
     "sprc_cast_f32_to_16": (i32, [vp, vp, sz, i32, vp]),
     "sprc_cast_f32_to_x3": (i32, [vp, vp, i64, i32, vp]),
     "sprc_absmax_bf16": (i32, [vp, sz, vp, vp]),
+    "sprc_absmax_16": (i32, [vp, sz, i32, vp, vp]),
     "sprc_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "sprc_gemm_pair": (i32, [C.POINTER(GemmArgs), C.POINTER(GemmArgs), vp]),
     "sprc_layernorm": (i32, [C.POINTER(LayerNormArgs), vp]),

@@ -19,8 +19,9 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     SPRC_REQUIRE(a->dtype != SPRC_FP8 || (a->w_scale != nullptr && a->a_scale > 0.f && !a->max32 && b == nullptr),
                  "sprc_gemm(fp8): needs w_scale, a_scale > 0; no max32 / paired launch");
     SPRC_REQUIRE(a->out_dtype != SPRC_FP8 || a->out_scale > 0.f, "sprc_gemm: SPRC_FP8 output needs out_scale > 0");
-    SPRC_REQUIRE(a->out_dtype != SPRC_F16 || a->dtype == SPRC_F16 || (a->dtype == SPRC_BF16 && a->act == SPRC_ACT_NONE && !a->resid && !a->max32),
-                 "sprc_gemm: SPRC_F16 output takes fp16 operands, or bf16 operands and a plain (bias-only) epilogue");
+    SPRC_REQUIRE(a->out_dtype != SPRC_F16 || a->dtype == SPRC_F16 ||
+                     ((a->dtype == SPRC_BF16 || a->dtype == SPRC_FP8) && a->act == SPRC_ACT_NONE && !a->resid && !a->max32),
+                 "sprc_gemm: SPRC_F16 output takes fp16 operands, or bf16 / fp8 operands and a plain (bias-only) epilogue");
     const int es = (int)dtype_size(a->dtype);
     SPRC_REQUIRE(((int64_t)a->K * es) % 128 == 0, "sprc_gemm: K=%d must be a multiple of %d", a->K, 128 / es);
     SPRC_REQUIRE((a->lda * es) % 16 == 0 && (a->ldw * es) % 16 == 0, "sprc_gemm: lda/ldw must be 16-byte multiples");

@@ -1181,8 +1181,8 @@ static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st
     if constexpr (sizeof(T) != 1) { if (a->max32) return launch<T, float, SPRC_ACT_NONE, true>(p, st); }
     if constexpr (std::is_same<T, bf16_t>::value) {     // residual-branch delta (validated by the caller: plain epilogue)
         if (a->out_dtype == SPRC_F16) return launch<T, f16_t, SPRC_ACT_NONE, false>(p, st);
-    } else if constexpr (!std::is_same<T, f16_t>::value) {
-        if (a->out_dtype == SPRC_F16) { set_error("sprc_gemm: SPRC_F16 output needs bf16 or fp16 operands"); return SPRC_EUNSUPPORTED; }
+    } else if constexpr (sizeof(T) == 4) {
+        if (a->out_dtype == SPRC_F16) { set_error("sprc_gemm: SPRC_F16 output needs bf16, fp16 or fp8 operands"); return SPRC_EUNSUPPORTED; }
     }
     if constexpr (sizeof(T) == 1) {                     // fp8 operands: the three epilogues of the fp8 ViT path
         if (a->out_dtype == SPRC_FP8) {
@@ -1193,6 +1193,7 @@ static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st
             }
         }
         if (a->act == SPRC_ACT_NONE && a->out_dtype == SPRC_BF16) return launch<T, bf16_t, SPRC_ACT_NONE, false>(p, st);
+        if (a->act == SPRC_ACT_NONE && a->out_dtype == SPRC_F16) return launch<T, f16_t, SPRC_ACT_NONE, false>(p, st);
         if (a->act == SPRC_ACT_NONE && a->out_dtype == SPRC_F32) return launch<T, float, SPRC_ACT_NONE, false>(p, st);
         set_error("sprc_gemm(fp8): unsupported epilogue (act %d, out_dtype %d)", a->act, a->out_dtype);
         return SPRC_EUNSUPPORTED;

@@ -386,11 +386,12 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     // that reads x next: the branch GEMM writes its output as fp16 into the h buffer (dead at that point; the LN overwrites
     // it in place with its bf16 result) and the LN kernel adds it to the fp32 residual stream (sum32 = x) before the
     // statistics.  Off by default (see fuse_add_enabled: no net gain, and it costs parity).
-    const bool fp8 = m->fp8 != 0;
+    const bool fp8 = m->fp8 != 0, fp8_qkv = m->fp8 == SPRC_FP8_ALL;
     const bool fuse_add = dt == SPRC_BF16 && !fp8 && fuse_add_enabled(1);
-    SPRC_REQUIRE(!fp8 || (dt == SPRC_BF16 && D % 128 == 0 && F % 128 == 0), "sprc_vit_forward: the fp8 path needs a bf16 model with width, mlp %% 128 == 0");
-    SPRC_REQUIRE(!(fp8 && m->calib_amax), "sprc_vit_forward: calibrate on the bf16 model, not on the fp8 one");
-    float* calib = (dt == SPRC_BF16 && !fp8) ? m->calib_amax : nullptr;
+    SPRC_REQUIRE(m->fp8 == 0 || m->fp8 == SPRC_FP8_ALL || m->fp8 == SPRC_FP8_MLP, "sprc_vit_forward: fp8 = %d", m->fp8);
+    SPRC_REQUIRE(!fp8 || (is16(dt) && D % 128 == 0 && F % 128 == 0), "sprc_vit_forward: the fp8 path needs a 16-bit model with width, mlp %% 128 == 0");
+    SPRC_REQUIRE(!(fp8 && m->calib_amax), "sprc_vit_forward: calibrate on the 16-bit model, not on the fp8 one");
+    float* calib = (is16(dt) && !fp8) ? m->calib_amax : nullptr;
     for (int l = 0; l < m->depth; ++l) {                    // enqueue layer by layer, alternating streams: both stay fed
         const sprc_vit_layer& L = m->layers[l];
         for (int i = 0; i < nparts; ++i) {
@@ -400,9 +401,14 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
                 // fc1's GELU output quantised in its epilogue; attention and proj stay bf16; residual stream / LN fp32.
                 // h (bf16-sized) holds the fp8 operand: half its bytes, leading dimension D bytes.
                 const Fp8Scales s_qkv{L.qkv_ws, L.s_ln1, 0.f}, s_fc1{L.fc1_ws, L.s_ln2, 1.0f / L.s_mlp}, s_fc2{L.fc2_ws, L.s_mlp, 0.f};
-                RUN(lnorm(q.ps, SPRC_FP8, q.Mp, D, q.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, q.h, ID_MAP, nullptr, nullptr, 1.0f / L.s_ln1));
-                RUN(gemm(q.ps, SPRC_FP8, SPRC_BF16, q.Mp, 3 * D, D, q.h, D, L.qkv, q.qkv, 3 * D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP,
-                         nullptr, 0, &s_qkv));
+                if (fp8_qkv) {
+                    RUN(lnorm(q.ps, SPRC_FP8, q.Mp, D, q.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, q.h, ID_MAP, nullptr, nullptr, 1.0f / L.s_ln1));
+                    RUN(gemm(q.ps, SPRC_FP8, dt, q.Mp, 3 * D, D, q.h, D, L.qkv, q.qkv, 3 * D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP,
+                             nullptr, 0, &s_qkv));
+                } else {
+                    RUN(lnorm(q.ps, dt, q.Mp, D, q.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, q.h));
+                    RUN(gemm(q.ps, dt, dt, q.Mp, 3 * D, D, q.h, D, L.qkv, q.qkv, 3 * D));
+                }
                 RUN(attn(q.ps, dt, q.Bp, m->heads, T, T, m->head_dim, q.qkv, 3 * D, q.qkv + D * es, 3 * D, q.qkv + 2 * D * es, 3 * D,
                          q.ctx, D, nullptr, scale));
                 RUN(gemm(q.ps, dt, SPRC_F32, q.Mp, D, D, q.ctx, D, L.proj, q.x, D, SPRC_ACT_NONE, q.x, D));
@@ -419,7 +425,7 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
             } else {
                 RUN(lnorm(q.ps, dt, q.Mp, D, q.x, L.ln1_w, L.ln1_b, m->ln_eps, nullptr, q.h));
             }
-            if (calib) RUN(sprc_absmax_bf16(q.h, (size_t)q.Mp * D, calib + l * 3 + 0, q.ps));
+            if (calib) RUN(sprc_absmax_16(q.h, (size_t)q.Mp * D, dt, calib + l * 3 + 0, q.ps));
             RUN(gemm(q.ps, dt, dt, q.Mp, 3 * D, D, q.h, D, L.qkv, q.qkv, 3 * D));
             RUN(attn(q.ps, dt, q.Bp, m->heads, T, T, m->head_dim, q.qkv, 3 * D, q.qkv + D * es, 3 * D, q.qkv + 2 * D * es, 3 * D,
                      q.ctx, D, nullptr, scale));
@@ -430,9 +436,9 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
                 RUN(gemm(q.ps, dt, SPRC_F32, q.Mp, D, D, q.ctx, D, L.proj, q.x, D, SPRC_ACT_NONE, q.x, D));
                 RUN(lnorm(q.ps, dt, q.Mp, D, q.x, L.ln2_w, L.ln2_b, m->ln_eps, nullptr, q.h));
             }
-            if (calib) RUN(sprc_absmax_bf16(q.h, (size_t)q.Mp * D, calib + l * 3 + 1, q.ps));
+            if (calib) RUN(sprc_absmax_16(q.h, (size_t)q.Mp * D, dt, calib + l * 3 + 1, q.ps));
             RUN(gemm(q.ps, dt, dt, q.Mp, F, D, q.h, D, L.fc1, q.mlp, F, m->act));
-            if (calib) RUN(sprc_absmax_bf16(q.mlp, (size_t)q.Mp * F, calib + l * 3 + 2, q.ps));
+            if (calib) RUN(sprc_absmax_16(q.mlp, (size_t)q.Mp * F, dt, calib + l * 3 + 2, q.ps));
             if (fuse_add) {
                 RUN(gemm(q.ps, dt, SPRC_F16, q.Mp, D, F, q.mlp, F, L.fc2, q.h, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP, q.scratch,
                          scratch_bytes));

@@ -150,8 +150,16 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_fp8_kernel(LnPa
 
 // amax[0] = max(amax[0], max |x|) over a bf16 tensor (calibration of the fp8 activation scales; values are >= 0, so the
 // integer ordering of the fp32 bit patterns is the numeric one and atomicMax on the bits is exact)
+template <bool F16>
 __global__ __launch_bounds__(256) void absmax_bf16_kernel(const uint16_t* __restrict__ x, size_t n, float* amax) {
     float m = 0.f;
+    if constexpr (F16) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+            m = fmaxf(m, fabsf((float)__builtin_bit_cast(_Float16, x[i])));
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0 && m == m) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(m));
+        return;
+    }
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (size_t)gridDim.x * 256 * 8) {
         if (i + 8 <= n) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(x + i);
@@ -546,11 +554,15 @@ extern "C" int sprc_qformer_mask(const int64_t* attention_mask, float* out, int3
     return SPRC_OK;
 }
 
-extern "C" int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s) {
-    SPRC_REQUIRE(x && amax && n > 0 && ((uintptr_t)x % 16) == 0, "sprc_absmax_bf16: bad arguments");
+extern "C" int sprc_absmax_16(const void* x, size_t n, int32_t dtype, float* amax, sprc_stream s) {
+    SPRC_REQUIRE(x && amax && n > 0 && ((uintptr_t)x % 16) == 0 && (dtype == SPRC_BF16 || dtype == SPRC_F16), "sprc_absmax_16: bad arguments");
     const size_t blocks = (n / 8 + 255) / 256;
-    hipLaunchKernelGGL(absmax_bf16_kernel, dim3((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048)), dim3(256), 0, (hipStream_t)s,
-                       reinterpret_cast<const uint16_t*>(x), n, amax);
-    SPRC_CHECK_LAUNCH("sprc_absmax_bf16");
+    const dim3 grid((unsigned)(blocks < 2048 ? (blocks ? blocks : 1) : 2048));
+    if (dtype == SPRC_F16)
+        hipLaunchKernelGGL(absmax_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, reinterpret_cast<const uint16_t*>(x), n, amax);
+    else
+        hipLaunchKernelGGL(absmax_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, reinterpret_cast<const uint16_t*>(x), n, amax);
+    SPRC_CHECK_LAUNCH("sprc_absmax_16");
     return SPRC_OK;
 }
+extern "C" int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s) { return sprc_absmax_16(x, n, SPRC_BF16, amax, s); }

@@ -2,6 +2,7 @@
 """Where does a 16-bit engine's score error come from?  Full-depth planted case (the sizes of tests/golden/planted_full_eva.npz),
 fp32 engine as the truth (it matches the reference to 3.5e-6): the ViT and the Q-Former of the 16-bit engine are swapped in one at a
 time.  python tools/err_split.py [fp16|bf16]"""
+import os
 import sys
 from pathlib import Path
 
@@ -15,8 +16,8 @@ from sprc_amd.config import get_config  # noqa: E402
 
 DEV = "cuda:0"
 dtype = sys.argv[1] if len(sys.argv) > 1 else "fp16"
-g = np.load(ROOT / "tests/golden/planted_full_eva.npz", allow_pickle=False)
-cfg = get_config("pretrain")
+g = np.load(ROOT / "tests/golden" / os.environ.get("SPRC_GOLDEN", "planted_full_eva.npz"), allow_pickle=False)     # or planted_full_clip.npz (ViT-L)
+cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
 sd = synth.make_state_dict(cfg, seed=int(g["seed"]), planted=True)
 images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]), planted=True)
 ref = torch.from_numpy(g["ref_index"]).to(DEV)

@@ -2,6 +2,7 @@
 """Which layer kinds of the Q-Former need split-precision (SPRC_F16X3) operands?  For each mask: max|dsim| of the fp16 engine against
 the full-depth planted golden (the reference's scores) and the time of the Q-Former calls of one bench step (128 images, 233 queries).
     python tools/x3_sweep.py [mask ...]        (masks as integers, engine.X3_* bits; default: a one-out / one-in sweep)"""
+import os
 import sys
 from pathlib import Path
 
@@ -15,8 +16,8 @@ from sprc_amd.config import get_config  # noqa: E402
 
 DEV = "cuda:0"
 NAMES = ["qkv", "attn_out", "cross_q", "cross_out", "ffn_in", "ffn_out", "ckv", "heads"]
-g = np.load(ROOT / "tests/golden/planted_full_eva.npz", allow_pickle=False)
-cfg = get_config("pretrain")
+g = np.load(ROOT / "tests/golden" / os.environ.get("SPRC_GOLDEN", "planted_full_eva.npz"), allow_pickle=False)     # or planted_full_clip.npz (ViT-L)
+cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
 sd = synth.make_state_dict(cfg, seed=int(g["seed"]), planted=True)
 images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]), planted=True)
 ref = torch.from_numpy(g["ref_index"]).to(DEV)
