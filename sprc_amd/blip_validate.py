@@ -28,15 +28,36 @@ def _device():
 
 
 def model_fingerprint(model) -> str:
-    """sha256 over the model's state dict (names, shapes, bytes): the identity of the checkpoint that produced a feature
-    store.  Features of one checkpoint must never be ranked with the queries of another."""
+    """The identity of the checkpoint that produced a feature store: sha256 over (name, shape, dtype, two 64-bit integer
+    checksums of the BITS) of every tensor of the state dict.  Features of one checkpoint must never be ranked with the queries
+    of another.  The checksums -- sum of the 32-bit words and sum of word x (position mod 65521 + 1), wrapping int64 -- are
+    computed where the tensor lives (integer arithmetic: exact and order-independent, the same on CPU and GPU); hashing the
+    4 GB of a ViT-g state dict on the host took ~4 s of every run that named a store."""
     import hashlib
     h = hashlib.sha256()
     for k, v in sorted(model.state_dict().items()):
-        t = v.detach().to("cpu").contiguous()
+        t = v.detach().contiguous()
         h.update(k.encode()); h.update(str(tuple(t.shape)).encode()); h.update(str(t.dtype).encode())
-        h.update(t.reshape(-1).view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+        if not t.numel():
+            continue
+        b = t.reshape(-1).view(torch.uint8)
+        if b.numel() % 4:
+            b = torch.cat([b, b.new_zeros(4 - b.numel() % 4)])
+        w = b.view(torch.int32).to(torch.int64)
+        pos = torch.arange(w.numel(), device=w.device, dtype=torch.int64).remainder_(65521).add_(1)
+        h.update(str((int(w.sum()), int((w * pos).sum()))).encode())
     return h.hexdigest()
+
+
+def _raw_store_dtype(model) -> torch.dtype:
+    """The dtype a store may keep raw ViT embeddings in without changing a bit downstream: the 16-bit operand format the engine
+    rounds them to when it reads them (K|V projection of the fusion pass / the rerank) -- unless that projection runs on split-
+    precision operands of the fp32 values (engine.X3_CKV in the query-side mask) or the engine is fp32."""
+    from . import _lib as L, engine as E
+    eng = model.engine()
+    if eng.dt == L.SPRC_F16 and not (eng.x3_fuse & E.X3_CKV):
+        return torch.float16
+    return torch.bfloat16 if eng.dt == L.SPRC_BF16 else torch.float32
 
 
 def _gallery(dataset, model, cache, tag, backbone, dtype, num_workers: int = 2):
@@ -54,7 +75,7 @@ def _gallery(dataset, model, cache, tag, backbone, dtype, num_workers: int = 2):
             return (feats, raw), names
         print(f"{path}: written by another checkpoint ({meta.get('checkpoint_sha256', '?')[:16]}), re-encoding")
     (feats, raw), names = extract_index_blip_features(dataset, model, num_workers=num_workers)
-    save_index(path, feats, names, raw=raw, backbone=backbone, compute_dtype=dtype, checkpoint_sha256=fp)
+    save_index(path, feats, names, raw=raw, backbone=backbone, compute_dtype=dtype, checkpoint_sha256=fp, raw_dtype=_raw_store_dtype(model))
     return (feats, raw), names
 
 

@@ -552,6 +552,307 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming kernel, second form (round 3): the K / V tiles go global -> LDS by DMA (`buffer_load_dwordx4 ... lds`) and V is
+// read back TRANSPOSED by the LDS unit (`ds_read_b64_tr_b16`).  Ablations of the first form (tools/attn_abl.sh, 135 us on the box
+// of that run): without the tile math 113 us, without loads + commit 100 us -- the staging path (two register sets of 16-B loads,
+// the commit with its eight transposing 4-B LDS writes and 16 VALU per thread and tile) weighed as much as the arithmetic.  Here
+//   * a tile is 32 key rows of K (13 slots of 16 B: 208-B pitch, conflict-free for the fragments' ds_read_b128) and 32 rows of V
+//     (12 slots: 192-B pitch = 48 dwords, which spreads the four rows x two 16-column groups that a 32-lane half of a transposing
+//     read touches over all 64 banks).  A DMA instruction writes 64 consecutive slots, lane by lane, from any 64 global addresses:
+//     slot (key, chunk) <- chunk of that key's row; padding slots of K take the zeros of an out-of-range offset; slots past the K
+//     region and the V slots at d >= head_dim are masked off (EXEC) -- V's are filled once, and hold the ONES column (V[k][dh] = 1:
+//     the softmax denominator falls out of the P.V MFMAs as before);
+//   * no staging registers, no commit: a ring of NBUF tiles, per key tile ONE counted `s_waitcnt vmcnt` + ONE barrier, then the
+//     DMA of tile kt + NBUF - 1 is issued into the buffer every wave has just left;
+//   * V^T fragments (A operand of O^T += V^T P^T): lane i of a 16-lane group hands the address of 8-byte piece i of a
+//     [4 keys][16 d] block (row i / 4, columns 4 (i % 4) ..) and receives column i (tools/tr_probe.hip checks this on the hardware).
+// The arithmetic of a tile (S^T = K Q^T, lazy rescale, exp2, O^T += V^T P^T) is the first form's.
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t voffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
+}
+__device__ __forceinline__ u32x2 attn_tr_read(const char* lds_src) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)lds_src));
+}
+
+// the value lane (l ^ 32) holds: v_permlane32_swap (gfx950) exchanges the two 32-lane halves in the VALU -- __shfl_xor(x, 32) is a
+// ds_bpermute, an LDS round trip in the middle of every tile's dependency chain
+__device__ __forceinline__ float attn_other_half(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+template <int DHP, bool ONES, int NW, bool F16, int NBUF>
+__global__ __launch_bounds__(64 * NW, NBUF == 2 ? 4 : 3) void attn_dma_kernel(AttnParams p, int nqb, int xcd_map) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = DHP / 16, DT = DHP / 32, CPR = DHP / 8;
+    constexpr int KSL = CPR + 1, VSL = 12;                     // 16-B slots per K / V row
+    constexpr int KROW = KSL * 16, VROW = VSL * 16;
+    constexpr int KQ = (32 * KSL + 63) / 64, VQ = 32 * VSL / 64;          // DMA wave-instructions per tile
+    constexpr int KBYTES = KQ * 1024, VBYTES = 32 * VROW, BUF = KBYTES + VBYTES;   // K region: whole instructions (the last one's tail is padding)
+    constexpr int NQ = KQ + VQ, NI = (NQ + NW - 1) / NW;                 // ... and per wave (instruction q = n NW + wave: K pieces first, then V)
+    constexpr int D = NBUF - 1;                                          // tiles in flight ahead of the one being multiplied
+    static_assert(CPR <= VSL && (32 * VSL) % 64 == 0 && NBUF >= 2 && NBUF <= 3, "tile geometry");
+    static_assert(NW * 32 * (DHP * 2 + 16) <= NBUF * BUF, "output strips fit in the tile ring");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, half = lane >> 5;
+    int b, h, qb;
+    if (xcd_map == 2) { const int x = blockIdx.x & 7, i = blockIdx.x >> 3; qb = i % nqb; h = (i / nqb) % p.H; b = (i / (nqb * p.H)) * 8 + x; }
+    else if (xcd_map == 1) { const int x = blockIdx.x & 7, i = blockIdx.x >> 3; qb = i % nqb; const int bh = (i / nqb) * 8 + x; b = bh / p.H; h = bh % p.H; }
+    else { const int bh = blockIdx.x / nqb; qb = blockIdx.x % nqb; b = bh / p.H; h = bh % p.H; }
+    const int dh = p.dh;
+    const int nkt = (p.Tk + 31) >> 5;
+    const bool ragged = (p.Tk & 31) != 0;
+
+    // ---- this lane's share of a tile's DMA: instruction q = n * NW + wave writes slots [64 q, 64 q + 64) ----
+    const __amdgpu_buffer_rsrc_t rs_k = attn_rsrc(p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2,
+                                                  (uint32_t)((int64_t)(p.Tk - 1) * p.ldk * 2 + dh * 2));
+    const __amdgpu_buffer_rsrc_t rs_v = attn_rsrc(p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2,
+                                                  (uint32_t)((int64_t)(p.Tk - 1) * p.ldv * 2 + dh * 2));
+    uint32_t d_off[NI];
+    bool d_ok[NI];
+    const bool d_last = (NI - 1) * NW + wave < NQ;                       // does this wave issue its NI-th instruction? (wave-uniform)
+    const uint32_t kstep = 32 * p.ldk * 2, vstep = 32 * p.ldv * 2;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+        const int q = n * NW + wave;
+        if (q < KQ) {
+            const int slot = q * 64 + lane, key = slot / KSL, c = slot - key * KSL;
+            d_ok[n] = true;
+            // padding (chunks past head_dim, slots past the 32 rows): zeros through the descriptor's range check
+            d_off[n] = (slot < 32 * KSL && c * 8 < dh) ? (uint32_t)(key * p.ldk * 2 + c * 16) : ATTN_OOB;
+        } else {
+            const int slot = (q - KQ) * 64 + lane, key = slot / VSL, c = slot - key * VSL;
+            d_ok[n] = c * 8 < dh;
+            d_off[n] = (uint32_t)(key * p.ldv * 2 + c * 16);
+            // the V slots no DMA writes, in every buffer of the ring: zeros, and the ONES column at d = head_dim
+            if (q < NQ && c * 8 >= dh) {
+                const u32x4 fill = {(ONES && c * 8 == dh) ? (F16 ? 0x3c00u : 0x3f80u) : 0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int u = 0; u < NBUF; ++u) *reinterpret_cast<u32x4*>(smem + u * BUF + KBYTES + slot * 16) = fill;
+            }
+        }
+    }
+    // the next tile in key order into ring buffer `buf`: issued unconditionally, also past the last tile (rows >= Tk are out of the
+    // descriptor's range: zeros, no memory traffic), so that the wait below is one constant per wave
+    auto fetch = [&](int buf) {
+        char* dst = smem + buf * BUF;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int q = n * NW + wave;
+            if (n + 1 < NI || NQ % NW == 0 || d_last) {
+                if (q < KQ) {
+                    attn_dma16(rs_k, dst + q * 1024, d_off[n]);
+                    d_off[n] += kstep;
+                } else {
+                    if (d_ok[n]) attn_dma16(rs_v, dst + q * 1024, d_off[n]);     // EXEC-masked: the fill of the other slots stays
+                    d_off[n] += vstep;
+                }
+            }
+        }
+    };
+    auto wait_tile = [&]() {                   // all but this wave's newest (D - 1) tiles' DMAs have landed
+        if constexpr (D == 1) attn_wait_vmcnt<0>();
+        else if (NQ % NW == 0 || d_last) attn_wait_vmcnt<(D - 1) * NI>();
+        else attn_wait_vmcnt<(D - 1) * (NI - 1)>();
+    };
+    const bool small = ragged && p.Tk - (nkt - 1) * 32 <= 4;     // the last tile holds at most 4 real keys
+    const int n_main = small ? nkt - 1 : nkt;
+    const float sc = p.scale * LOG2E;
+    // V^T fragment addressing: group g = lane >> 4 = 2 half + sub; the lane hands piece i = lane & 15 of the block
+    // [keys k0 + 4 half .. +4][d = 32 dt + 16 sub .. +16]: row i >> 2, columns 4 (i & 3)
+    const int vi = lane & 15, vsub = (lane >> 4) & 1;
+    const int v_lane = (4 * half + (vi >> 2)) * VROW + (16 * vsub + 4 * (vi & 3)) * 2;
+    const int k_lane = r32 * KROW + half * 16;
+    // Q^T fragments first (B operand): lane (q = r32, half) holds Q[q][ks*16 + half*8 .. +8]; the DMAs queue up behind them
+    const int qt = qb * NW + wave;
+    const int qrow = min(qt * 32 + r32, p.Tq - 1);
+    const char* qptr = p.q + (((int64_t)b * p.Tq + qrow) * p.ldq + (int64_t)h * dh) * 2;
+    u32x4 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 16 + half * 8;
+        u32x4 val = {0u, 0u, 0u, 0u};
+        if (d0 < dh) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
+        qf[ks] = val;
+    }
+
+#pragma unroll
+    for (int u = 0; u < D; ++u) fetch(u);
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // tail: the tile holds padded keys (a wave-uniform run-time flag: a second instantiation of this body for the last tile, next
+    // to tail_small, took the allocator from 119 registers to 53 spilled ones)
+    auto tile = [&](int kt, const char* sK, bool tail) {
+        const char* sV = sK + KBYTES;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* krow = sK + k_lane;
+        // (two accumulation chains over even / odd k-steps, 16 more additions: 125.9 vs 123.8 us -- the chain is not what the tile waits for)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(krow + ks * 32);
+            s = mfma16<F16>(kf, qf[ks], s);
+        }
+        if (tail) {                             // padded keys: key of reg r = kt*32 + (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= p.Tk) s[r] = -INFINITY;
+        }
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, attn_other_half(mx)) * sc;               // every tile holds >= 1 real key: finite
+        if (__any(mx - m_run > RESCALE_LOG2)) {                  // always in the first tile (m_run = -inf), rarely afterwards
+            const float m_new = (mx - m_run > RESCALE_LOG2) ? mx : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], sc, -m_run));
+        u32x4 pf[2];
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pf[j][e] = pack16x2<F16>(s[8 * j + 2 * e], s[8 * j + 2 * e + 1]);
+                if constexpr (!ONES) psum += rounded_pair_sum<F16>(pf[j][e]);
+            }
+        }
+        if constexpr (!ONES) l_run += psum;
+        // V^T fragments (the compiler moves the reads up into the exponentials)
+        u32x4 vf[DT][2];
+        const char* vb = sV + v_lane;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x2 lo = attn_tr_read(vb + (16 * j) * VROW + dt * 64);
+                const u32x2 hi = attn_tr_read(vb + (16 * j + 8) * VROW + dt * 64);
+                vf[dt][j] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                o[dt] = mfma16<F16>(vf[dt][j], pf[j], o[dt]);
+    };
+
+    // A last tile with at most 4 real keys (the ViT's 257 tokens: ONE).  They are keys 0..3 of the tile = registers 0..3 of the half-0
+    // lanes, so the softmax arithmetic runs on 4 values instead of 16 and P.V on the first 16-key step only, whose upper eight keys
+    // carry zero probabilities (their V fragment is not even read): ~45 % of a full tile, and the ninth tile was 11 % of the key loop.
+    auto tail_small = [&](int kt, const char* sK) {
+        const char* sV = sK + KBYTES;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* krow = sK + k_lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 kf = *reinterpret_cast<const u32x4*>(krow + ks * 32);
+            s = mfma16<F16>(kf, qf[ks], s);
+        }
+        const int tk = p.Tk - kt * 32;
+        float sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = (half == 0 && r < tk) ? s[r] : -INFINITY;
+        float mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        mx = fmaxf(mx, attn_other_half(mx)) * sc;               // key 0 is real: finite
+        if (__any(mx - m_run > RESCALE_LOG2)) {
+            const float m_new = (mx - m_run > RESCALE_LOG2) ? mx : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], sc, -m_run));       // exp2(-inf) = 0 for the padded keys
+        const u32x4 pf = {pack16x2<F16>(sv[0], sv[1]), pack16x2<F16>(sv[2], sv[3]), 0u, 0u};
+        if constexpr (!ONES) l_run += rounded_pair_sum<F16>(pf[0]) + rounded_pair_sum<F16>(pf[1]);
+        const char* vb = sV + v_lane;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const u32x2 lo = attn_tr_read(vb + dt * 64);
+            o[dt] = mfma16<F16>(u32x4{lo[0], lo[1], 0u, 0u}, pf, o[dt]);
+        }
+    };
+
+    // iteration kt: tiles kt .. kt + D - 1 are in flight or landed; wait for tile kt (this wave's share: everything but the DMAs of
+    // its newest D - 1 tiles), barrier (every wave's share is visible, and every wave has left tile kt - 1's buffer), refill that
+    // buffer with tile kt + D, multiply tile kt
+    int buf = 0, nxt = D % NBUF;
+    for (int kt = 0; kt < n_main; ++kt) {
+        wait_tile();
+        __syncthreads();
+        fetch(nxt);
+        tile(kt, smem + buf * BUF, ragged && kt == nkt - 1);
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+        nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+    }
+    if (small) {                              // (nothing left to fetch)
+        attn_wait_vmcnt<0>();
+        __syncthreads();
+        tail_small(nkt - 1, smem + buf * BUF);
+    }
+    float l_tot;
+    if constexpr (ONES) {
+        static_assert(DHP == 96, "ones row: head_dim 88 in a 96-row tile");
+        l_tot = __shfl(o[2][12], r32, 64);       // row dh = 88 of O^T: tile dt = 2, d_local = 24 -> reg 12 of the half-0 lanes
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
+    const float inv = 1.0f / l_tot;
+    constexpr int ORS = DHP * 2 + 16;
+    attn_wait_vmcnt<0>();                     // the DMAs issued past the last tile still write into the ring
+    __syncthreads();                          // every wave is done reading K/V tiles
+    char* so = smem + wave * (32 * ORS);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = dt * 32 + 8 * g + 4 * half;
+            if (d0 < dh) {
+                uint2 pk;
+                pk.x = pack16x2<F16>(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv);
+                pk.y = pack16x2<F16>(o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(so + r32 * ORS + d0 * 2) = pk;
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    char* obase = p.out + (((int64_t)b * p.Tq + qt * 32) * p.ldo + (int64_t)h * dh) * 2;
+    auto store_rows = [&](int cpr) {          // 16-B chunks per output row
+        for (int idx = lane; idx < 32 * cpr; idx += 64) {
+            const int row = idx / cpr, c = idx - row * cpr;
+            if (qt * 32 + row < p.Tq)
+                *reinterpret_cast<u32x4*>(obase + (int64_t)row * p.ldo * 2 + c * 16) = *reinterpret_cast<const u32x4*>(so + row * ORS + c * 16);
+        }
+    };
+    if (ONES) store_rows(11);                 // head_dim 88 (compile-time divisor: the run-time division cost ~25 VALU per piece)
+    else if (dh == DHP) store_rows(DHP / 8);
+    else store_rows(dh >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
 // exact fp32: one wave per query row; lanes = keys for QK^T, lanes = head dims for PV.
 constexpr int F32_MAXK = 9;     // keys per lane -> Tk <= 576 (the rerank's 514 = 2 x 257 encoder tokens)
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
@@ -655,6 +956,20 @@ static int launch_stream(const AttnParams& p, hipStream_t st) {
     return SPRC_OK;
 }
 
+template <int DHP, bool ONES, int NW, bool F16, int NBUF>
+static int launch_dma(const AttnParams& p, hipStream_t st) {
+
+    constexpr int BUF = (32 * (DHP / 8 + 1) + 63) / 64 * 1024 + 32 * 12 * 16;       // K region in whole DMA instructions + V region
+    constexpr int LDS = NBUF * BUF;
+    const int nqb = ((p.Tq + 31) / 32 + NW - 1) / NW;
+    const int bh = p.B * p.H;
+    static const int xcd = [] { const char* e = getenv("SPRC_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    const int xmap = !xcd ? 0 : (xcd == 3 && (bh % 8) == 0) ? 1 : (p.B % 8) == 0 ? 2 : (bh % 8) == 0 ? 1 : 0;
+    hipLaunchKernelGGL((attn_dma_kernel<DHP, ONES, NW, F16, NBUF>), dim3(bh * nqb), dim3(64 * NW), LDS, st, p, nqb, xmap);
+    SPRC_CHECK_LAUNCH("sprc_attention(16-bit, streaming, DMA)");
+    return SPRC_OK;
+}
+
 }  // namespace sprc
 
 namespace sprc {
@@ -674,6 +989,23 @@ static int attention16(const sprc_attention_args* a, const AttnParams& p, bool t
     // 5- and 9-wave workgroups measured 268 / 170 us against 125: fewer co-resident workgroups).
     // (SPRC_ATTN_STREAM=0 keeps the resident-K/V kernel for A/B runs)
     static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
+    // SPRC_ATTN_DMA: 0 = the first streaming form (register staging), 2 / 3 = the DMA form with a ring of that many tiles
+    static const int dma = [] { const char* e = getenv("SPRC_ATTN_DMA"); return e ? atoi(e) : 2; }();
+    if (stream && dma && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
+        static const int nw4 = [] { const char* e = getenv("SPRC_ATTN_NW"); return e ? atoi(e) == 4 : 0; }();
+        if (dma == 2 && nw4) {
+            if (a->head_dim <= 64) return launch_dma<64, false, 4, F16, 2>(p, st);
+            if (a->head_dim == 88) return launch_dma<96, true, 4, F16, 2>(p, st);
+        }
+        if (dma == 2) {
+            if (a->head_dim <= 64) return launch_dma<64, false, 3, F16, 2>(p, st);
+            if (a->head_dim == 88) return launch_dma<96, true, 3, F16, 2>(p, st);
+            return launch_dma<96, false, 3, F16, 2>(p, st);
+        }
+        if (a->head_dim <= 64) return launch_dma<64, false, 3, F16, 3>(p, st);
+        if (a->head_dim == 88) return launch_dma<96, true, 3, F16, 3>(p, st);
+        return launch_dma<96, false, 3, F16, 3>(p, st);
+    }
     if (stream && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
         if (a->head_dim <= 64) return launch_stream<64, false, 3, F16>(p, st);
         if (a->head_dim == 88) return launch_stream<96, true, 3, F16>(p, st);     // denominator from the ones row of the padded V^T tile

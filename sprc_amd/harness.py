@@ -13,6 +13,7 @@ from __future__ import annotations
 
 from operator import itemgetter
 import os
+import time
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -104,11 +105,19 @@ class _ThreadLoader:
     without the cost of starting worker processes (a fork-server worker imports torch: ~1 s each, 11 s for twelve on the MI355X
     box's host, for a gallery the engine encodes in 1.6 s) and without pickling every decoded image through a pipe."""
 
-    def __init__(self, dataset, batch_size: int, threads: int, ahead: int = 3):
+    def __init__(self, dataset, batch_size: int, threads: int, ahead: int = 3, first: int = 32):
+        """first: size of the FIRST batch (the rest of that batch follows as the second one, every later batch keeps its boundaries):
+        the GPU starts on 32 images after ~25 ms instead of waiting ~150 ms for 128 to be decoded and transformed -- the pipeline's
+        fill was all of the difference between a gallery pass from files and the engine on resident tensors (tools/c2_e2e.py)."""
         self.ds, self.bs, self.threads, self.ahead = dataset, batch_size, max(1, threads), ahead
+        n = len(dataset)
+        cuts = list(range(0, n, batch_size)) + [n]
+        if 0 < first < min(batch_size, n):
+            cuts.insert(1, first)
+        self.spans = list(zip(cuts[:-1], cuts[1:]))
 
     def __len__(self):
-        return (len(self.ds) + self.bs - 1) // self.bs
+        return len(self.spans)
 
     def __iter__(self):
         from collections import deque
@@ -116,12 +125,12 @@ class _ThreadLoader:
         n = len(self.ds)
         with ThreadPoolExecutor(max_workers=self.threads) as pool:
             pending = deque()
-            starts = iter(range(0, n, self.bs))
+            spans = iter(self.spans)
 
             def submit():
-                s = next(starts, None)
+                s = next(spans, None)
                 if s is not None:
-                    pending.append([pool.submit(self.ds.__getitem__, i) for i in range(s, min(s + self.bs, n))])
+                    pending.append([pool.submit(self.ds.__getitem__, i) for i in range(*s)])
 
             for _ in range(self.ahead):
                 submit()
@@ -178,7 +187,10 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     wanted = set() if keep_raw in (False, None) else (set(keep_raw) if subset else None)
     rows: Dict[int, torch.Tensor] = {}
     tf_stream = None
+    trace = [] if os.environ.get("SPRC_TRACE_GALLERY") else None     # per batch: host seconds waiting for the loader / issuing the transform / the encode
+    t_prev = time.perf_counter()
     for batch_names, images in tqdm(loader):
+        t_got = time.perf_counter()
         if gpu_tf is not None:       # uint8 images go through the GPU transform; items a worker already transformed (modes the GPU
             from .data_utils import is_transformed      # path does not reproduce: palette, alpha, ...) are finished tensors
             # on a side stream: a host-to-device copy from pageable memory blocks the host until everything queued before it on
@@ -191,7 +203,11 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
             torch.cuda.current_stream(dev).wait_stream(tf_stream)
             images.record_stream(torch.cuda.current_stream(dev))
         images = images.to(dev, non_blocking=True)
+        t_tf = time.perf_counter()
         f, r = blip_model.extract_target_features(images, mode="mean")
+        if trace is not None:
+            trace.append((t_got - t_prev, t_tf - t_got, time.perf_counter() - t_tf))
+            t_prev = time.perf_counter()
         if raw_dtype is not None:
             r = r.to(raw_dtype)
         if save_memory:
@@ -204,6 +220,10 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
         else:
             raws.append(r)
         names.extend(batch_names)
+    if trace:
+        w, t, e = (sum(x[i] for x in trace) for i in range(3))
+        print(f"[gallery trace] {len(trace)} batches: host waited {w * 1e3:.0f} ms for the loader (first batch {trace[0][0] * 1e3:.0f}), spent "
+              f"{t * 1e3:.0f} ms issuing transforms (first {trace[0][1] * 1e3:.0f}) and {e * 1e3:.0f} ms issuing encodes (first {trace[0][2] * 1e3:.0f})")
     if subset:
         return (torch.vstack(feats), RawStore(len(names), rows)), names
     return (torch.vstack(feats), torch.vstack(raws)), names

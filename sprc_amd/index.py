@@ -4,8 +4,12 @@ The reference re-encodes the whole gallery on every run (`src/utils.py:46-77` re
 `save_memory` only moves them to the CPU, `:67-69`).  A gallery is encoded once here and kept as ONE safetensors file:
 
     feats      [N, 32, 256]  fp32   unit-norm Q-Former query features (what `inference` ranks against)
-    raw        [N, 257, D]   fp32   optional: ViT embeddings of the images that can be *reference* images of a query
-                                    (CIRR/FashionIQ take references from the gallery itself); omitted for pure galleries
+    raw        [N, 257, D]   fp32, or the engine's 16-bit operand dtype (`raw_dtype`)
+                                    optional: ViT embeddings of the images that can be *reference* images of a query
+                                    (CIRR/FashionIQ take references from the gallery itself); omitted for pure galleries.
+                                    fp16 / bf16: the format the engine rounds them to anyway when it reads them (the K|V
+                                    projection operand of the fusion pass and of the rerank): half the bytes, the same bits
+                                    downstream (the rounding is idempotent); load_index hands them back as fp32
     metadata   names (JSON list, row order), backbone, dtype the features were computed in, format version,
                checkpoint_sha256 = fingerprint of the state dict that produced the features (blip_validate refuses a store
                written by another checkpoint)
@@ -25,7 +29,7 @@ FORMAT = "sprc-index-1"
 
 
 def save_index(path, feats: torch.Tensor, names: Sequence[str], raw: Optional[torch.Tensor] = None, backbone: str = "",
-               compute_dtype: str = "", checkpoint_sha256: str = "") -> None:
+               compute_dtype: str = "", checkpoint_sha256: str = "", raw_dtype: torch.dtype = torch.float32) -> None:
     from safetensors.torch import save_file
     if feats.dim() != 3 or feats.shape[1] != 32:
         raise ValueError(f"feats must be [N,32,E], got {tuple(feats.shape)}")
@@ -35,7 +39,9 @@ def save_index(path, feats: torch.Tensor, names: Sequence[str], raw: Optional[to
         raise ValueError("gallery names must be unique (they are the join key of the relative datasets)")
     tensors = {"feats": feats.detach().to("cpu", torch.float32).contiguous()}
     if raw is not None:
-        tensors["raw"] = raw.detach().to("cpu", torch.float32).contiguous()
+        if raw_dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            raise ValueError(f"raw_dtype {raw_dtype}")
+        tensors["raw"] = raw.detach().to(raw_dtype).to("cpu").contiguous()          # rounded where the tensor lives (the GPU), then copied
     meta = {"format": FORMAT, "names": json.dumps(list(names)), "backbone": backbone, "compute_dtype": compute_dtype,
             "checkpoint_sha256": checkpoint_sha256}
     path = Path(path)
@@ -57,5 +63,5 @@ def load_index(path, device="cpu", with_raw: bool = True) -> Tuple[Tuple[torch.T
     if len(names) != feats.shape[0]:
         raise ValueError(f"{path}: {len(names)} names for {feats.shape[0]} rows")
     feats = feats.to(device)
-    raw = raw.to(device) if raw is not None else None
+    raw = raw.to(device).float() if raw is not None else None
     return (feats, raw), names, {k: v for k, v in meta.items() if k != "names"}

@@ -151,6 +151,15 @@ def test_feature_store_round_trip(tmp_path):
     assert r3 is None and torch.equal(f3, feats) and n3 == names
     save_index(tmp_path / "noraw.safetensors", feats, names)
     assert load_index(tmp_path / "noraw.safetensors")[0][1] is None
+    # raw kept in the engine's 16-bit operand format: comes back as fp32 holding exactly the rounded values (idempotent rounding:
+    # what the engine makes of it is what it makes of the fp32 original)
+    for dt in (torch.float16, torch.bfloat16):
+        save_index(tmp_path / "raw16.safetensors", feats, names, raw=raw, raw_dtype=dt)
+        (f4, r4), _, _ = load_index(tmp_path / "raw16.safetensors")
+        assert r4.dtype == torch.float32 and torch.equal(r4, raw.to(dt).float()) and torch.equal(r4.to(dt), raw.to(dt)) and torch.equal(f4, feats)
+        assert (tmp_path / "raw16.safetensors").stat().st_size < 0.75 * p.stat().st_size
+    with pytest.raises(ValueError, match="raw_dtype"):
+        save_index(tmp_path / "bad.safetensors", feats, names, raw=raw, raw_dtype=torch.float64)
     with pytest.raises(ValueError, match="unique"):
         save_index(tmp_path / "dup.safetensors", feats, ["a"] * 37)
     with pytest.raises(ValueError, match="one entry per"):
@@ -207,5 +216,39 @@ def test_query_loaders_stay_in_the_main_process_and_gallery_workers_only_decode(
     got = list(H._ThreadLoader(Items(), batch_size=4, threads=3))
     assert [b[0] for b in got] == [["n0", "n1", "n2", "n3"], ["n5", "n6", "n7"], ["n8", "n9", "n10"]]
     assert all(int(t[0, 0, 0]) == int(n[1:]) for b in got for n, t in zip(*b)) and len(H._ThreadLoader(Items(), 4, 3)) == 3
+    # a short FIRST batch (the pipeline's fill): the first batch's remainder follows, later boundaries stay where they were
+    ramp = H._ThreadLoader(Items(), batch_size=4, threads=2, first=1)
+    assert [b[0] for b in ramp] == [["n0"], ["n1", "n2", "n3"], ["n5", "n6", "n7"], ["n8", "n9", "n10"]] and len(ramp) == 4
+    assert [b[0] for b in H._ThreadLoader(Items(), batch_size=16, threads=2, first=32)] == [[f"n{i}" for i in range(11) if i != 4]]
     names, imgs = H._collate_ragged([("n0", torch.zeros(3, 4, 3, dtype=torch.uint8)), None, ("n1", torch.zeros(5, 2, 3, dtype=torch.uint8))])
     assert names == ["n0", "n1"] and [tuple(i.shape) for i in imgs] == [(3, 4, 3), (5, 2, 3)]
+
+
+def test_model_fingerprint_sees_every_bit():
+    """blip_validate.model_fingerprint (the key that ties a feature store to the checkpoint that produced it): integer
+    checksums of the tensors' bits -- equal for equal state dicts, different after a one-ulp change, after swapping two elements
+    (the position-weighted sum), after renaming a tensor or changing its dtype."""
+    import torch
+    from sprc_amd.blip_validate import model_fingerprint
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(1)
+            self.a = torch.nn.Parameter(torch.randn((5, 7), generator=g))
+            self.register_buffer("b", torch.randn((3,), generator=g).to(torch.bfloat16))      # 6 bytes: padded to whole words
+            self.register_buffer("ids", torch.arange(4, dtype=torch.int64))
+
+    m = M()
+    f0 = model_fingerprint(m)
+    assert f0 == model_fingerprint(M()) and len(f0) == 64
+    with torch.no_grad():
+        m.a[2, 3] = torch.nextafter(m.a[2, 3].detach(), torch.tensor(10.0))
+    f1 = model_fingerprint(m)
+    m2 = M()
+    with torch.no_grad():
+        x, y = m2.a[0, 0].clone(), m2.a[4, 6].clone()
+        m2.a[0, 0], m2.a[4, 6] = y, x
+    m3 = M()
+    m3.b = m3.b.to(torch.float16)
+    assert len({f0, f1, model_fingerprint(m2), model_fingerprint(m3)}) == 4

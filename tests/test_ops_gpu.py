@@ -350,6 +350,26 @@ def test_attention_random_shapes():
             torch.testing.assert_close(out.float().double(), ref, atol=tol, rtol=tol, msg=lambda m: f"{what}\n{m}")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dh", [64, 72, 88, 96])
+def test_attention_streaming_key_tails(dtype, dh):
+    """The streaming (DMA ring + transposing LDS reads) kernel of the ViT blocks on every kind of last key tile: none (Tk % 32 == 0),
+    the short path of <= 4 real keys (257 tokens: one), the masked generic one; head dims with and without the ones column (88) and
+    without padding (64, 96); query counts that leave waves of a workgroup without rows."""
+    B, H = 2, 3
+    D = H * dh
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    for Tq, Tk in ((257, 257), (130, 256), (257, 258), (200, 260), (161, 261), (257, 272), (193, 287), (129, 33), (257, 36)):
+        q, k, v = (_rand((B, t, D), 900 + i + Tk).to(tdt) for i, t in enumerate((Tq, Tk, Tk)))
+        scale = dh ** -0.5
+        ref = _attn_ref(q.float().view(B, Tq, H, dh).transpose(1, 2), k.float().view(B, Tk, H, dh).transpose(1, 2),
+                        v.float().view(B, Tk, H, dh).transpose(1, 2), scale).transpose(1, 2).reshape(B * Tq, D)
+        out = E.attention(q.to(DEV).view(B * Tq, D), k.to(DEV).view(B * Tk, D), v.to(DEV).view(B * Tk, D), B, H, Tq, Tk, dh, D, D, D, scale).cpu()
+        assert out.dtype == tdt
+        tol = 2e-2 if dtype == "bf16" else 3e-3
+        torch.testing.assert_close(out.float().double(), ref, atol=tol, rtol=tol, msg=lambda m: f"Tq={Tq} Tk={Tk} dh={dh} {dtype}\n{m}")
+
+
 def test_attention_packed_qkv_layout():
     # q/k/v interleaved as [token][3][H][dh] exactly like the ViT qkv GEMM output (eva_vit.py:125)
     B, H, T, dh = 2, 16, 257, 88
