@@ -430,6 +430,12 @@ def main():
         planted_goldens(GOLD / "planted_full_eva.npz", n_img=96, n_q=48, vit_depth=None)
     if a.full and want("planted_clip"):      # the same on config C5's backbone (CLIP ViT-L, 24 blocks): the fp8 path's structured case
         planted_goldens(GOLD / "planted_full_clip.npz", n_img=96, n_q=48, vit_depth=None, model_type="pretrain_vitL")
+    # second draws of weights, images and queries (seed 1) of both full-depth cases: the 16-bit engines' max|dsim| is an extreme-value
+    # statistic over 4608 scores -- one draw says little about how much room there is under 1e-3
+    if a.full and want("planted_full_s1"):
+        planted_goldens(GOLD / "planted_full_eva_s1.npz", n_img=96, n_q=48, vit_depth=None, seed=1)
+    if a.full and want("planted_clip_s1"):
+        planted_goldens(GOLD / "planted_full_clip_s1.npz", n_img=96, n_q=48, vit_depth=None, model_type="pretrain_vitL", seed=1)
     if a.full and want("full_eva"):
         model_goldens("pretrain", None, n_img=2, n_q=3, out=GOLD / "full_eva.npz")
     if a.full and want("full_clip"):
