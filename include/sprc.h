@@ -171,7 +171,8 @@ typedef struct {
 int sprc_attention(const sprc_attention_args* a, sprc_stream s);
 
 /* Patch extraction for the 14x14/stride-14 conv (eva_vit.py:196,203; clip_vit.py:160,173-175):
- * images [B,3,S,S] fp32 -> rows [B*G*G, k_pad] (`dtype`), column = c*P*P + i*P + j, zero padded. */
+ * images [B,3,S,S] fp32 -> rows [B*G*G, k_pad] (`dtype`), column = c*P*P + i*P + j, zero padded.
+ * dtype SPRC_F16X3: rows [B*G*G, 3 k_pad] = [hi | lo | hi] (fp16). */
 int sprc_im2row(const float* images, void* rows, int32_t B, int32_t image, int32_t patch, int32_t k_pad,
                 int32_t dtype, sprc_stream s);
 
@@ -257,6 +258,10 @@ typedef struct {
                                                  * fc2 inputs, updated by sprc_vit_forward -- the calibration pass of the fp8 scales */
     float* pre_ln_out;                          /* optional device array [B, tokens, width] fp32: receives the INPUT of ln_vision (the ViT's last
                                                  * residual stream) -- what the training step needs for ln_vision's gradient (blip2.py:81) */
+    int32_t patch_x3;                           /* dtype SPRC_F16 only, 1: the patch embedding runs on split-precision operands -- patch.w is
+                                                 * [W_hi | W_hi | W_lo], [width, 3 patch_k_pad], the patch rows are SPRC_F16X3.  Its output IS the
+                                                 * residual stream's first value: an fp16 rounding there is carried through every block
+                                                 * (tools/fq_vit.py: 27 % of the fp16 ViT's error variance, for 0.1 ms) */
 } sprc_vit_model;
 
 typedef struct {

@@ -434,6 +434,9 @@ def main():
     # statistic over 4608 scores -- one draw says little about how much room there is under 1e-3
     if a.full and want("planted_full_s1"):
         planted_goldens(GOLD / "planted_full_eva_s1.npz", n_img=96, n_q=48, vit_depth=None, seed=1)
+    # a larger draw (256 gallery images x 128 queries = 32768 scores, seed 2): the tail of the 16-bit engines' error distribution
+    if a.full and want("planted_big"):
+        planted_goldens(GOLD / "planted_big_eva.npz", n_img=256, n_q=128, vit_depth=None, seed=2)
     if a.full and want("planted_clip_s1"):
         planted_goldens(GOLD / "planted_full_clip_s1.npz", n_img=96, n_q=48, vit_depth=None, model_type="pretrain_vitL", seed=1)
     if a.full and want("full_eva"):

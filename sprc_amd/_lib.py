@@ -89,7 +89,7 @@ class VitModel(C.Structure):
                 ("act", i32), ("tokens", i32), ("patch_size", i32), ("image", i32), ("patch_k_pad", i32),
                 ("has_ln_pre", i32), ("ln_eps", f32), ("ln_vision_eps", f32), ("patch", Linear),
                 ("cls", vp), ("pos", vp), ("ln_pre_w", vp), ("ln_pre_b", vp), ("ln_vision_w", vp), ("ln_vision_b", vp),
-                ("layers", C.POINTER(VitLayer)), ("fp8", i32), ("calib_amax", vp), ("pre_ln_out", vp)]
+                ("layers", C.POINTER(VitLayer)), ("fp8", i32), ("calib_amax", vp), ("pre_ln_out", vp), ("patch_x3", i32)]
 
 
 class QfLayer(C.Structure):

@@ -126,7 +126,7 @@ struct VitBufs { void *rows, *h, *qkv, *ctx, *mlp; float *pout, *x; };
 static size_t vit_plan(const sprc_vit_model* m, int B, Bump& b, VitBufs& v) {
     const size_t es = dtype_size(m->dtype);
     const size_t M = (size_t)B * m->tokens, P = (size_t)B * (m->tokens - 1), D = m->width;
-    v.rows = b.take(P * m->patch_k_pad * es);
+    v.rows = b.take(P * m->patch_k_pad * es * (m->patch_x3 ? 3 : 1));
     v.pout = (float*)b.take(P * D * 4);
     v.x = (float*)b.take(M * D * 4);
     v.h = b.take(M * D * es);
@@ -340,8 +340,14 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     const size_t es = dtype_size(dt);
     const size_t pout_bytes = (size_t)P * D * 4;
     const float scale = 1.0f / sqrtf((float)m->head_dim);                       // eva_vit.py:74
-    RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, dt, st));
-    RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D));
+    SPRC_REQUIRE(!m->patch_x3 || dt == SPRC_F16, "sprc_vit_forward: patch_x3 is a mode of the fp16 model");
+    if (m->patch_x3) {                                      // split-precision patch embedding: K' = 3 k_pad, ~fp32 products
+        RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, SPRC_F16X3, st));
+        RUN(gemm(st, dt, SPRC_F32, P, D, 3 * m->patch_k_pad, v.rows, 3 * m->patch_k_pad, m->patch, v.pout, D));
+    } else {
+        RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, dt, st));
+        RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D));
+    }
     RUN(sprc_vit_assemble(v.pout, m->cls, m->pos, v.x, B, T, D, st));
     if (m->has_ln_pre) RUN(lnorm(st, dt, M, D, v.x, m->ln_pre_w, m->ln_pre_b, m->ln_eps, v.x, nullptr));
     // ---- transformer blocks.  SPRC_VIT_STREAMS=2 runs the two halves of the batch on two streams (the caller's and one

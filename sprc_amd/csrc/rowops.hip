@@ -269,7 +269,12 @@ __global__ void im2row_kernel(const float* __restrict__ img, void* __restrict__ 
             const int64_t b = row / (G * G);
             v = img[((b * 3 + c) * S + (py * P + i)) * (int64_t)S + (px * P + j)];
         }
-        if constexpr (KIND != 0) reinterpret_cast<uint16_t*>(rows)[e] = (uint16_t)(pack16x2<KIND == 2>(v, 0.f) & 0xffffu);
+        if constexpr (KIND == 3) {              // SPRC_F16X3: [hi | lo | hi], row width 3 kpad
+            _Float16 hi, lo;
+            split_f16(v, hi, lo);
+            _Float16* r = reinterpret_cast<_Float16*>(rows) + row * 3 * (int64_t)kpad + k;
+            r[0] = hi; r[kpad] = lo; r[2 * kpad] = hi;
+        } else if constexpr (KIND != 0) reinterpret_cast<uint16_t*>(rows)[e] = (uint16_t)(pack16x2<KIND == 2>(v, 0.f) & 0xffffu);
         else reinterpret_cast<float*>(rows)[e] = v;
     }
 }
@@ -531,6 +536,7 @@ extern "C" int sprc_im2row(const float* images, void* rows, int32_t B, int32_t i
     const int64_t total = (int64_t)B * (image / patch) * (image / patch) * k_pad;
     if (dtype == SPRC_BF16) hipLaunchKernelGGL(im2row_kernel<1>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
     else if (dtype == SPRC_F16) hipLaunchKernelGGL(im2row_kernel<2>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
+    else if (dtype == SPRC_F16X3) hipLaunchKernelGGL(im2row_kernel<3>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
     else hipLaunchKernelGGL(im2row_kernel<0>, dim3(grid_for(total, 256, 256 * 16)), dim3(256), 0, (hipStream_t)s, images, rows, B, image, patch, k_pad);
     SPRC_CHECK_LAUNCH("sprc_im2row");
     return SPRC_OK;

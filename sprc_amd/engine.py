@@ -7,6 +7,7 @@ computation of the retrieval path runs in the HIP kernels.  There is no CPU fall
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -237,6 +238,8 @@ class Engine:
         else:
             self.x3_image = self.x3_fuse = X3_ALL if qformer_x3 is True else int(qformer_x3)
         self.x3 = self.x3_image | self.x3_fuse      # what the weights are packed for
+        # fp16 ViT: split-precision patch embedding (SPRC_PATCH_X3=0: A/B switch)
+        self.patch_x3 = self.dt == L.SPRC_F16 and os.environ.get("SPRC_PATCH_X3", "1") != "0"
         if self.x3 and self.dt != L.SPRC_F16:
             raise ValueError("qformer_x3 (split-precision Q-Former) is a mode of the fp16 engine")
         self.max_batch = max_batch
@@ -268,6 +271,18 @@ class Engine:
         if not (self.x3 & kind):
             return self._lin(w, b)
         w32 = w.detach().to(device=self.device, dtype=torch.float32)
+        hi = w32.to(torch.float16)
+        lo = (w32 - hi.float()).to(torch.float16)
+        w3 = torch.cat([hi, hi, lo], dim=1).contiguous()
+        self._keep.append(w3)
+        return L.Linear(w3.data_ptr(), None if b is None else self._f32(b).data_ptr())
+
+    def _lin_patch(self, w: torch.Tensor, b: Optional[torch.Tensor]) -> L.Linear:
+        """The patch embedding's weights [width, 3 P P] padded to patch_k_pad columns; fp16 engine: split precision, [W_hi | W_hi | W_lo]
+        (sprc_vit_model.patch_x3: the embedding's output is the first value of the residual stream, its rounding error is never averaged away)."""
+        if not self.patch_x3:
+            return self._lin(w, b, self.patch_k_pad)
+        w32 = torch.nn.functional.pad(w.detach().to(device=self.device, dtype=torch.float32), (0, self.patch_k_pad - w.shape[1]))
         hi = w32.to(torch.float16)
         lo = (w32 - hi.float()).to(torch.float16)
         w3 = torch.cat([hi, hi, lo], dim=1).contiguous()
@@ -319,11 +334,11 @@ class Engine:
         m.tokens, m.patch_size, m.image, m.patch_k_pad = v.tokens, v.patch, v.image, self.patch_k_pad
         m.has_ln_pre, m.ln_eps, m.ln_vision_eps = int(v.ln_pre), v.ln_eps, self.cfg.ln_vision_eps
         if v.kind == "eva_g":
-            m.patch = self._lin(sd[p + "patch_embed.proj.weight"].reshape(D, -1), sd[p + "patch_embed.proj.bias"], self.patch_k_pad)
+            m.patch = self._lin_patch(sd[p + "patch_embed.proj.weight"].reshape(D, -1), sd[p + "patch_embed.proj.bias"])
             m.cls = self._f32(sd[p + "cls_token"].reshape(D)).data_ptr()
             m.pos = self._f32(sd[p + "pos_embed"].reshape(v.tokens, D)).data_ptr()
         else:
-            m.patch = self._lin(sd[p + "conv1.weight"].reshape(D, -1), None, self.patch_k_pad)
+            m.patch = self._lin_patch(sd[p + "conv1.weight"].reshape(D, -1), None)
             m.cls = self._f32(sd[p + "class_embedding"].reshape(D)).data_ptr()
             m.pos = self._f32(sd[p + "positional_embedding"].reshape(v.tokens, D)).data_ptr()
             m.ln_pre_w = self._f32(sd[p + "ln_pre.weight"]).data_ptr()
@@ -332,6 +347,7 @@ class Engine:
         m.ln_vision_b = self._f32(sd["ln_vision.bias"]).data_ptr()
         m.layers = C.cast(layers, C.POINTER(L.VitLayer))
         m.fp8 = int(self.fp8_mode)
+        m.patch_x3 = int(self.patch_x3)
         self._vit_layers, self.vit = layers, m
 
     def _pack_qformer(self, sd):

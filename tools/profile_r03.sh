@@ -25,3 +25,5 @@ python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | gr
 bash tools/trace_top.sh --pipeline 0 --qf-streams 1 > $O/trace_top.txt 2>&1
 rm -rf $O/pb/kt $O/pb/pmc_* $O/pmc/p? $O/pmc/kt $R/gpurun_out/trace_top/kt
 head -c 400 $O/bench_n1.json; echo; tail -40 $O/pmc.log
+SPRC_TRACE_GALLERY=1 TMPDIR=/tmp timeout 900 python tools/c2_e2e.py 2>&1 | grep -v "Warning\|^/opt\|it/s\|warn" | grep "trace\|c2_e2e" > $O/c2_e2e.txt
+cat $O/c2_e2e.txt
