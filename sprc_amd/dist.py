@@ -84,10 +84,14 @@ class ShardedRanker:
     """Ranks queries against a gallery sharded over the ranks of `group`."""
 
     def __init__(self, local_feats: torch.Tensor, index_base: int, sim_fn: SimFn = _hip_sim, topk_fn: TopkFn = _hip_topk,
-                 group=None, always_exchange: Optional[bool] = None):
+                 group=None, always_exchange: Optional[bool] = None, sim_budget_bytes: int = 2 << 30):
         """always_exchange (default: environment SPRC_DIST_ALWAYS_EXCHANGE=1): run both all_gathers and the merge even in a
-        one-rank group -- same result, and the RCCL path of a 1-GPU box is then the path an 8-GPU node takes."""
+        one-rank group -- same result, and the RCCL path of a 1-GPU box is then the path an 8-GPU node takes.
+        sim_budget_bytes: the local score matrix sim[nq, n_local] fp32 is never held whole when it is larger than this: the queries
+        are ranked in blocks of budget / (4 n_local) rows -- the reference materialises nq x N (validate_blip.py:253-254; config C5's
+        10 000 x 125 000 per GPU would be 5 GB), here top-k and the listed scores are taken block by block: same bits, bounded memory."""
         self.feats, self.base, self.sim_fn, self.topk_fn, self.group = local_feats, int(index_base), sim_fn, topk_fn, group
+        self.sim_budget_bytes = int(sim_budget_bytes)
         if always_exchange is None:
             import os
             always_exchange = os.environ.get("SPRC_DIST_ALWAYS_EXCHANGE", "0") == "1"
@@ -109,14 +113,22 @@ class ShardedRanker:
         if select is not None:
             fusion = fusion.index_select(0, select.to(fusion.device))
         nq, n_local = fusion.shape[0], self.feats.shape[0]
-        sim = self.sim_fn(fusion.contiguous(), self.feats)
-        vals, idx = self.topk_fn(sim, k, None, self.base)
-        lv = None
-        if listed is not None:                                                                  # scores of the listed items this rank owns
-            col = listed.to(device=sim.device, dtype=torch.int64) - self.base
-            own = (col >= 0) & (col < n_local)
-            lv = torch.where(own, sim.gather(1, col.clamp(0, max(n_local - 1, 0))) if n_local else torch.zeros_like(col, dtype=sim.dtype),
-                             torch.full(col.shape, float("-inf"), dtype=sim.dtype, device=sim.device))
+        fusion = fusion.contiguous()
+        qb = max(1, min(max(nq, 1), self.sim_budget_bytes // (4 * max(n_local, 1))))           # query rows per block of local scores
+        vals_b, idx_b, lv_b = [], [], []
+        for s in range(0, max(nq, 1), qb):
+            sim = self.sim_fn(fusion[s:s + qb], self.feats)
+            v, i = self.topk_fn(sim, k, None, self.base)
+            vals_b.append(v)
+            idx_b.append(i)
+            if listed is not None:                                                              # scores of the listed items this rank owns
+                col = listed[s:s + qb].to(device=sim.device, dtype=torch.int64) - self.base
+                own = (col >= 0) & (col < n_local)
+                lv_b.append(torch.where(own, sim.gather(1, col.clamp(0, max(n_local - 1, 0))) if n_local else torch.zeros_like(col, dtype=sim.dtype),
+                                        torch.full(col.shape, float("-inf"), dtype=sim.dtype, device=sim.device)))
+            del sim
+        vals, idx = (vals_b[0], idx_b[0]) if len(vals_b) == 1 else (torch.cat(vals_b), torch.cat(idx_b))
+        lv = None if listed is None else (lv_b[0] if len(lv_b) == 1 else torch.cat(lv_b))
         if not exchange:
             return (vals, idx) if listed is None else (vals, idx, lv)
         # exchange 2: ONE all_gather of [nq, k (score bits) + k (global index) + L (listed score bits)] int32 per rank

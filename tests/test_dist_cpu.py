@@ -74,3 +74,30 @@ def test_sharded_ranking_equals_single_process_world3_uneven():
             out = mgr.dict()
             mp.spawn(_worker, args=(3, _free_port(), n_total, nq_local, k, out), nprocs=3, join=True)
             assert out[0] and out[1] and out[2], (n_total, nq_local, k, dict(out))
+
+
+def test_local_scores_are_ranked_in_query_blocks_under_a_memory_budget():
+    """ShardedRanker.sim_budget_bytes: the local sim[nq, n_local] is produced and consumed in blocks of query rows when it would be
+    larger than the budget (config C5: 10 000 x 125 000 fp32 = 5 GB per GPU); top-k and the listed scores are the same bits as from
+    the whole matrix (one process, no group: the local half of `rank`)."""
+    from sprc_amd.dist import ShardedRanker
+    g = torch.Generator().manual_seed(11)
+    feats = ((torch.nn.functional.normalize(torch.randn((41, 32, 16), generator=g), dim=-1) * 8).round() / 8)
+    fusion = ((torch.nn.functional.normalize(torch.randn((23, 16), generator=g), dim=-1) * 8).round() / 8)
+    listed = torch.randint(-1, 41, (23, 6), generator=g)
+    calls = []
+
+    def sim_fn(f, t):
+        calls.append(f.shape[0])
+        return _cpu_sim(f, t)
+
+    whole = ShardedRanker(feats, 100, sim_fn=sim_fn, topk_fn=_cpu_topk).rank(fusion, 9, listed=listed + 100 * (listed >= 0))
+    assert calls == [23]
+    calls.clear()
+    blocks = ShardedRanker(feats, 100, sim_fn=sim_fn, topk_fn=_cpu_topk, sim_budget_bytes=5 * 41 * 4).rank(
+        fusion, 9, listed=listed + 100 * (listed >= 0))
+    assert calls == [5, 5, 5, 5, 3]
+    for a, b in zip(whole, blocks):
+        assert torch.equal(a, b)
+    want_v, want_i = O.topk_stable(O.similarity(fusion, feats).numpy(), 9)
+    assert np.array_equal(blocks[1].numpy(), want_i.astype(np.int32) + 100) and np.array_equal(blocks[0].numpy(), want_v)

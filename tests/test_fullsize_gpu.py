@@ -186,3 +186,11 @@ def test_c5_shard_bf16_ranking_at_scale():
         cand_v.append(lv); cand_i.append(li)
     mv, mi = E.topk(torch.cat(cand_v, 1).contiguous(), k, gidx=torch.cat(cand_i, 1).contiguous())
     assert torch.equal(mi, i) and torch.equal(mv, v)
+    # the library's ranker under a memory budget: local scores in blocks of 100 query rows (50 MB each instead of the 256-MB matrix;
+    # config C5's 10 000 queries: 5 GB), top-51 and the listed scores the same bits
+    from sprc_amd.dist import ShardedRanker
+    listed = torch.randint(-1, N, (nq, 6), generator=torch.Generator().manual_seed(6))
+    bv, bi, bl = ShardedRanker(feats, 0, sim_budget_bytes=100 * N * 4).rank(fusion, k, listed=listed)
+    assert torch.equal(bi, i) and torch.equal(bv, v)
+    col = listed.to(DEV).clamp(min=0)
+    assert torch.equal(bl, torch.where(listed.to(DEV) >= 0, sim.gather(1, col), torch.full_like(bl, float("-inf"))))
