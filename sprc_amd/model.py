@@ -51,10 +51,16 @@ class Blip2QformerCirAlignPrompt(nn.Module):
     PRETRAINED_MODEL_CONFIG_DICT = {k: k for k in MODEL_TYPES}     # align_prompt.py:38-42 ("coco" has no CIR use)
 
     def __init__(self, model_type: str = "pretrain", compute_dtype: str = "fp16", rank_dtype: str = "fp32",
-                 cfg: Optional[SprcConfig] = None, max_batch: int = 128, tokenizer=None, device="cpu"):
+                 cfg: Optional[SprcConfig] = None, max_batch: int = 128, tokenizer=None, device="cpu", train_vit_dtype: str = "fp32"):
+        """train_vit_dtype: dtype of the FROZEN ViT trunk inside a training step -- "fp32" (gradients within 1e-4 of the reference's fp32
+        graph) or "fp16" (what the reference's loop does: the trunk runs under `torch.cuda.amp.autocast`, blip_fine_tune_2.py:293; 64
+        ViT-g images per step then cost 45 ms instead of 500).  The Q-Former's forward and backward are fp32 either way."""
         super().__init__()
         self.cfg = cfg if cfg is not None else get_config(model_type)
         self.compute_dtype, self.rank_dtype, self.max_batch = compute_dtype, rank_dtype, max_batch
+        if train_vit_dtype not in ("fp32", "fp16"):
+            raise ValueError(f"train_vit_dtype {train_vit_dtype!r}")
+        self.train_vit_dtype = train_vit_dtype
         self.max_txt_len = self.cfg.max_txt_len
         for name, shape, _ in synth.param_specs(self.cfg):
             _register(self, name, shape, device)
@@ -213,11 +219,12 @@ class Blip2QformerCirAlignPrompt(nn.Module):
         return {"loss_itc": out[0], "loss_rtc": out[1], "loss_align": out[2]}
 
     def _train_engine(self) -> E.Engine:
-        """fp32 engine for the frozen ViT trunk of the training step (built once: the trunk does not train)."""
+        """engine for the frozen ViT trunk of the training step, in `train_vit_dtype` (built once: the trunk does not train)."""
         if getattr(self, "_tengine", None) is None:
             if self.device.type != "cuda":
                 raise L.SprcError("training runs on the MI355X HIP engine only; move the model to a GPU with .to('cuda') (there is no CPU fallback)")
-            self._tengine = E.Engine(self.cfg, dict(self.state_dict()), self.device, dtype="fp32", max_batch=self.max_batch)
+            self._tengine = E.Engine(self.cfg, dict(self.state_dict()), self.device, dtype=self.train_vit_dtype, max_batch=self.max_batch,
+                                     qformer_x3=0)
         return self._tengine
 
 

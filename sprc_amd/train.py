@@ -134,8 +134,10 @@ class _Linear:
 
 class TrainStep:
     def __init__(self, cfg, params: Dict[str, torch.Tensor], engine: E.Engine):
-        if engine.dt != L.SPRC_F32:
-            raise L.SprcError("the training step runs on the fp32 engine (exact-fp32 MFMA products)")
+        # `engine` runs the FROZEN ViT trunk only (vit_forward + its pre-ln_vision stream): fp32, or fp16 as under the reference's autocast
+        # (blip_fine_tune_2.py:293); everything that trains -- ln_vision, the Q-Former, the heads -- is computed here on the exact-fp32 GEMM
+        if engine.dt not in (L.SPRC_F32, L.SPRC_F16) or engine.fp8:
+            raise L.SprcError("the training step's frozen trunk runs on an fp32 or fp16 engine")
         self.cfg, self.P, self.eng = cfg, params, engine
         self.dev = engine.device
         self.k = _K(self.dev)

@@ -122,6 +122,35 @@ def test_backward_matches_the_reference_gradients(golden_dir):
     assert worst < 3e-4
 
 
+def test_fp16_frozen_trunk_in_the_training_step(golden_dir):
+    """train_vit_dtype="fp16": the frozen ViT of a training step on the fp16 engine, as the reference's loop runs it under autocast
+    (blip_fine_tune_2.py:293); ln_vision, the Q-Former and the heads stay on the fp32 path.  Losses within 1e-3 of the fp32-trunk step
+    (= of the reference's), every gradient within 2 % of its norm, same set of trained tensors."""
+    g, cfg, sd, model, batch = _train_case(golden_dir)
+    import json
+    w = json.loads(str(g["grad_weights"]))
+
+    def grads_of(m):
+        losses = m(batch)
+        sum(w[k] * v for k, v in losses.items()).backward()
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in losses.items()}, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l32, g32 = grads_of(model)
+    m16 = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=8, train_vit_dtype="fp16")
+    assert not m16.load_state_dict(sd, strict=False).missing_keys
+    m16 = m16.to(DEV)
+    m16.tokenizer = model.tokenizer
+    l16, g16 = grads_of(m16)
+    assert m16._train_engine().dt == L.SPRC_F16 and model._train_engine().dt == L.SPRC_F32
+    assert set(g16) == set(g32) and len(g16) > 300
+    worst = max(float((g16[n] - g32[n]).norm() / g32[n].norm().clamp_min(1e-12)) for n in g32 if float(g32[n].norm()) > 1e-8)
+    print(f"\n[train step, fp16 frozen trunk] losses {l16} vs fp32 trunk {l32}; worst relative gradient difference {worst:.2e} over {len(g16)} tensors")
+    assert all(abs(l16[k] - l32[k]) < 1e-3 for k in l32) and worst < 2e-2
+    with pytest.raises(ValueError):
+        Blip2QformerCirAlignPrompt(cfg=cfg, train_vit_dtype="bf16")
+
+
 def test_grad_scaler_and_adamw_step_as_in_the_reference_loop(golden_dir):
     """The reference's update (blip_fine_tune_2.py:257-262, :293-304): AdamW + GradScaler; a few steps on one batch must lower the loss,
     the inference engine must see the moved weights, and the ViT trunk must stay untouched."""
