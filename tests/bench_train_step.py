@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""One training step of the reference's loop (blip_fine_tune_2.py:281-304: forward of the three losses, `scaler.scale(loss).backward()`,
+"""(Not a test: a measurement script kept under tests/ because its CPU leg times the oracle, which only tests/, smoke() and bench.py's
+cpu_baseline may import.)  One training step of the reference's loop (blip_fine_tune_2.py:281-304: forward of the three losses, `scaler.scale(loss).backward()`,
 AdamW) on the HIP training path (sprc_amd/train.py: fp32 kernels, full-depth frozen ViT + trainable Q-Former / heads / ln_vision),
 timed on the GPU, next to the same step of the CPU oracle (torch autograd over oracle.training_losses) on a smaller batch.
-    python tools/train_bench.py [batch=32] [steps=5] [cpu_batch=4] [fp32|fp16 trunk]
+    python tests/bench_train_step.py [batch=32] [steps=5] [cpu_batch=4] [fp32|fp16 trunk]
 SURVEY.md section 8(f) N4: measurement of the training row (not the headline metric)."""
 import sys
 import time

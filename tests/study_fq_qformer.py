@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Fake-quantisation study of the Q-Former image pass (CPU, torch): which 16-bit rounding sites of the engine's Q-Former carry the
+"""(Not a test: a study script kept under tests/ because it imports the oracle, which only tests/, smoke() and bench.py's cpu_baseline may.)
+Fake-quantisation study of the Q-Former image pass (CPU, torch): which 16-bit rounding sites of the engine's Q-Former carry the
 feature error?  The fp32 restatement below follows oracle/sprc_oracle.py (qformer_forward, call shape (i)) with a rounding hook
 q(site, tensor) at every place the 16-bit engine stores or reads a 16-bit value; one site class is switched on at a time.
-    python tools/fq_qformer.py [fp16|bf16] [n_images]
+    python tests/study_fq_qformer.py [fp16|bf16] [n_images]
 """
 import sys
 from pathlib import Path
