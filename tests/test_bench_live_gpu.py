@@ -1,0 +1,39 @@
+"""The driver's contract on a LIVE run: `python bench.py --gpus 1 --steps K --warmup W` prints ONE JSON line with BASELINE.json's metric
+on its config, whole-job value consistent with the step time, the roofline object measured with HIP events inside the run, and (a
+second, longer invocation being the driver's business) a cpu_baseline object when it is not switched off."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(*args):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_live_bench_line():
+    base = json.loads((ROOT / "BASELINE.json").read_text())
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert base["metric"].startswith(d["metric"]) and d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "fp16" and "model" not in d["config"] and "CIRR-val" in d["config"]["workload"] and d["config"]["batch"] == 128
+    assert d["value"] == pytest.approx(128.0 / (d["ms_per_step"] * 1e-3), rel=1e-3) and 500 < d["value"] < 5000
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and r["frac"] == pytest.approx(r["achieved"] / r["peak"], abs=2e-4)
+    assert 0.2 < r["frac"] < 0.6 and 0.2 < r["step_frac"] < 0.6 and r["launches"] > 300 and r["avg_launch_ms"] > 0.05
+    assert r["step_frac"] == pytest.approx(r["step_alg_tflop"] / (d["ms_per_step"] * 1e-3) / r["peak"], rel=2e-3)
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None
+    # a dtype the reference does not benchmark with is refused by argparse, not silently accepted
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dtype", "int8"], cwd=ROOT, capture_output=True, text=True)
+    assert p.returncode != 0
