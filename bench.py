@@ -12,8 +12,10 @@ step    : one pass of the hot path over one batch of synthetic input =
 N > 1   : weak scaling, one rank per GPU: every rank owns a 2297-image gallery shard and its own queries; the only
           exchanges are the all_gather of fused query vectors and of per-shard top-k (sprc_amd/dist.py).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = bf16 MFMA GEMM, measured live with HIP events
-on the launch stream inside the timed region) and `cpu_baseline` (the fp32 CPU oracle on a bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel class = the 16-bit MFMA GEMM -- fp16 operands by default, the
+reference's own GPU precision -- measured live with HIP events on the launch stream inside the timed region; `frac` prices the
+class's ALGORITHMIC flops, `executed_tflop_per_step` says what the split-precision products add on top) and `cpu_baseline`
+(the fp32 CPU oracle on a bounded sample).
 """
 from __future__ import annotations
 
@@ -308,7 +310,8 @@ def main():
         lo = (i * BATCH) % (GALLERY - BATCH)
         s_img.wait_stream(main)
         s_fuse.wait_stream(main)
-        with torch.cuda.stream(s_img):
+        s_img.wait_event(done[(i - 1) % 2])                                       # batch i-1's ranking has read the whole gallery: the slice
+        with torch.cuda.stream(s_img):                                            # copy below must not land under it
             feats, _ = eng.qformer_image(buf)
             gallery[lo:lo + BATCH].copy_(feats)
         with torch.cuda.stream(s_fuse):
@@ -433,7 +436,12 @@ def main():
                          "timing": "HIP events on the launch stream(s), recorded on %d of the %d timed steps (every %dth; recording all "
                                    "of them costs 4.5 %% of the step); class time = union of the launch intervals, sum of launch "
                                    "durations = %.4f ms per launch" % (n_prof, a.steps, a.prof_every, pe.ms / max(pe.launches, 1)),
-                         "alg_flops_per_launch": round(pe.flops / max(pe.launches, 1), 1)},
+                         "alg_flops_per_launch": round(pe.flops / max(pe.launches, 1), 1),
+                         # launches x alg_flops_per_launch (<= step_alg_tflop: the class is part of the step), and what the launches
+                         # executed on top of it (split-precision products reduce over 3 K, the patch embedding over zero padding)
+                         "class_alg_tflop_per_step": round(pe.flops / n_prof * 1e-12, 3),
+                         "executed_tflop_per_step": round(pe.exec_flops / n_prof * 1e-12, 3),
+                         "executed_tflops": round(pe.exec_flops / max(pe.busy_ms, 1e-9) / 1e9, 1)},
             "kernels": kernels,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPRC_ABI_VERSION 3
+#define SPRC_ABI_VERSION 4
 
 enum { SPRC_OK = 0, SPRC_EINVAL = -1, SPRC_ELAUNCH = -2, SPRC_EWORKSPACE = -3, SPRC_EUNSUPPORTED = -4 };
 enum { SPRC_F32 = 0, SPRC_BF16 = 1,
@@ -67,9 +67,11 @@ const char* sprc_last_error(void);
  * recorded events and sums elapsed time, ALGORITHMIC flops and bytes per class. */
 enum { SPRC_K_GEMM_BF16 = 0, SPRC_K_GEMM_F32 = 1, SPRC_K_ATTN = 2, SPRC_K_ROWOPS = 3, SPRC_K_RANK = 4, SPRC_K_COUNT = 5 };
 typedef struct {
-    double ms, flops, bytes;   /* sum of launch durations; algorithmic flops and bytes */
+    double ms, flops, bytes;   /* sum of launch durations; ALGORITHMIC flops and bytes (sprc_gemm: 2 M N k_alg, see sprc_gemm_args) */
     int64_t launches;
     double busy_ms;            /* union of the launches' [start,end] intervals: == ms unless launches of the class overlapped */
+    double exec_flops;         /* ABI 4: flops the launches EXECUTED (sprc_gemm: 2 M N K with the launched K: split-precision products
+                                * reduce over K = 3 k_alg, the patch embedding over its zero-padded K); >= flops */
 } sprc_prof_entry;
 int sprc_prof_enable(int on);   /* 1 = start afresh, 0 = pause (records are kept for collect), 2 = resume.  Every recorded
                                  * launch costs two stream markers (~7 us of pipeline bubble): sample steps, do not record all */
@@ -112,6 +114,10 @@ typedef struct {
      * A = a_scale * A_q (per tensor) and W[n,:] = w_scale[n] * W_q[n,:] (per output channel; fp32 [N], 16-byte aligned).
      * out_dtype == SPRC_FP8: the result is multiplied by out_scale (= 1 / the consumer's a_scale) and saturated to +-448. */
     const float* w_scale; float a_scale; float out_scale;
+    /* ABI 4: the LOGICAL reduction length this product stands for, for the profiler's algorithmic flop count only (0 = K).
+     * A split-precision product over [hi | lo | hi] . [W_hi | W_hi | W_lo] launches K = 3 k_alg; the patch embedding launches its
+     * zero-padded K (640 for 588).  Never changes what is computed. */
+    int32_t k_alg;
 } sprc_gemm_args;
 int sprc_gemm(const sprc_gemm_args* a, sprc_stream s);
 

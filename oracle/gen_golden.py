@@ -213,13 +213,16 @@ def planted_targets(sim: np.ndarray, ref: np.ndarray, seed: int = 0, margin: flo
     return tgt, groups
 
 
-def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int = 4, seed: int = 0, model_type: str = "pretrain"):
+def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int = 4, seed: int = 0, model_type: str = "pretrain",
+                    trunk_fp16: bool = False):
     """Planted-structure ordering fixture: depth-4 ViT-g + the full Q-Former run by the REFERENCE on 160 gallery images
     and 72 composed queries; scores spread over > 1.0; targets at planned ranks; the reference's own
     compute_cirr_val_metrics / compute_fiq_val_metrics / generate_cirr_test_dicts evaluated on its own scores."""
     from torch.utils.data import Dataset
     cfg = get_config(model_type, vit_depth=vit_depth)
-    sd = synth.make_state_dict(cfg, seed=seed, planted=True)
+    # trunk_fp16: the checkpoint as a GPU-trained reference model saves it -- trunk Conv / Linear tensors hold fp16 values
+    # (synth.round_trunk_to_fp16); the reference's CPU path below still computes in fp32 (models/__init__.py:246-247)
+    sd = synth.make_state_dict(cfg, seed=seed, planted=True, trunk_fp16=trunk_fp16)
     model = ref_import.build_reference_model(cfg, sd)
     images = synth.make_images(n_img, seed=seed, planted=True)
     ids, mask, ref = synth.make_queries(n_q, n_img, seed=seed + 1)
@@ -276,7 +279,7 @@ def planted_goldens(out: Path, n_img: int = 160, n_q: int = 72, vit_depth: int =
     s_sorted = np.sort(sim, axis=1)
     gaps = np.diff(s_sorted, axis=1)
     np.savez_compressed(
-        out, model_type=model_type, vit_depth=cfg.vit.depth, seed=seed, n_img=n_img, n_q=n_q,
+        out, model_type=model_type, vit_depth=cfg.vit.depth, seed=seed, n_img=n_img, n_q=n_q, trunk_fp16=int(trunk_fp16),
         image_probe=_np(images[:4, :, 0, :4]), input_ids=ids.numpy(), attention_mask=mask.numpy(), ref_index=refn,
         tgt_index=tgt, groups=groups, sim=sim, fusion=fusion, feats_head=_np(feats[:4]), raw_head=_np(raw[:2][:, ROWS]),
         cirr=np.array(cirr, dtype=np.float64), fiq=np.array(fiq, dtype=np.float64),
@@ -439,6 +442,14 @@ def main():
         planted_goldens(GOLD / "planted_big_eva.npz", n_img=256, n_q=128, vit_depth=None, seed=2)
     if a.full and want("planted_clip_s1"):
         planted_goldens(GOLD / "planted_full_clip_s1.npz", n_img=96, n_q=48, vit_depth=None, model_type="pretrain_vitL", seed=1)
+    # the same cases on a checkpoint whose trunk Conv / Linear tensors hold fp16 VALUES -- what a GPU-trained reference checkpoint
+    # (the released SPRC weights included) contains; the reference's CPU path computes on them in fp32
+    if a.full and want("planted_big_h16"):
+        planted_goldens(GOLD / "planted_big_eva_h16.npz", n_img=256, n_q=128, vit_depth=None, seed=2, trunk_fp16=True)
+    if a.full and want("planted_full_h16"):
+        planted_goldens(GOLD / "planted_full_eva_h16.npz", n_img=96, n_q=48, vit_depth=None, trunk_fp16=True)
+    if a.full and want("planted_clip_h16"):
+        planted_goldens(GOLD / "planted_full_clip_h16.npz", n_img=96, n_q=48, vit_depth=None, model_type="pretrain_vitL", trunk_fp16=True)
     if a.full and want("full_eva"):
         model_goldens("pretrain", None, n_img=2, n_q=3, out=GOLD / "full_eva.npz")
     if a.full and want("full_clip"):

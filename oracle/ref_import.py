@@ -113,10 +113,17 @@ def install_shims() -> None:
     _installed = True
 
 
-def build_reference_model(cfg, state_dict, eval_mode: bool = True, variant: str = "align_prompt"):
+def build_reference_model(cfg, state_dict, eval_mode: bool = True, variant: str = "align_prompt", gpu_numerics: bool = False):
     """Construct the reference's Blip2QformerCirAlignPrompt (CPU, fp32) with `cfg` depths and load
     `state_dict` into it.  Returns the nn.Module.  Network-only constructors are replaced by the
-    same constructor calls without the download (SURVEY.md 8(c) shim 8)."""
+    same constructor calls without the download (SURVEY.md 8(c) shim 8).
+
+    gpu_numerics=True reproduces, on the CPU, the arithmetic the reference runs on a GPU (vit_precision="fp16", the class default):
+    the trunk's Conv / Linear weights go through the reference's OWN convert_weights_to_fp16 (eva_vit.py:410-425 / the clip_vit.py
+    twin, called where create_eva_vit_g :452-454 calls it: after the weights are loaded), the Q-Former, ln_vision and the heads stay
+    fp32, and `maybe_autocast` (blip2.py:36-44: "if on cpu, don't use autocast") is replaced by the CPU autocast context of the same
+    dtype -- the only line of behaviour that is changed.  Under it linear / conv / matmul run on fp16 operands and return fp16, the
+    residual stream, LayerNorm statistics and softmax stay fp32 (their inputs are fp32), as under torch.cuda.amp.autocast."""
     install_shims()
     import importlib
     from functools import partial
@@ -188,6 +195,10 @@ def build_reference_model(cfg, state_dict, eval_mode: bool = True, variant: str 
     if bad or msg.unexpected_keys:
         raise RuntimeError(f"state-dict mismatch: missing={bad[:8]} unexpected={msg.unexpected_keys[:8]}")
     model = model.float()
+    if gpu_numerics:
+        vmod = eva if v.kind == "eva_g" else clipv
+        vmod.convert_weights_to_fp16(model.visual_encoder)
+        model.maybe_autocast = lambda dtype=torch.float16: torch.autocast("cpu", dtype=dtype)
     if eval_mode:
         model.eval()
     return model

@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("SPRC_LIB_PATH") or (Path(__file__).resolve().par
 
 SPRC_F16X3 = 4                                        # storage layout of split-precision fp16 activations ([hi | lo | hi], sprc.h)
 SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: IEEE half (compute dtype since ABI 3); FP8: OCP e4m3fn operands
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 FP8_ALL, FP8_MLP = 1, 2                               # sprc_vit_model.fp8: qkv + fc1 + fc2, or fc1 + fc2 only, on e4m3fn operands
 DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16, "fp16": SPRC_F16, "f16": SPRC_F16,
@@ -36,7 +36,8 @@ class GemmArgs(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32), ("dtype", i32), ("out_dtype", i32), ("act", i32), ("max32", i32),
                 ("A", vp), ("lda", i64), ("amap", RowMap), ("W", vp), ("ldw", i64), ("bias", vp),
                 ("resid", vp), ("ldr", i64), ("C", vp), ("ldc", i64), ("cmap", RowMap),
-                ("scratch", vp), ("scratch_bytes", C.c_size_t), ("w_scale", vp), ("a_scale", f32), ("out_scale", f32)]
+                ("scratch", vp), ("scratch_bytes", C.c_size_t), ("w_scale", vp), ("a_scale", f32), ("out_scale", f32),
+                ("k_alg", i32)]
 
 
 class LayerNormArgs(C.Structure):
@@ -68,7 +69,8 @@ class AttentionBwdArgs(C.Structure):
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", i64), ("busy_ms", C.c_double)]
+    _fields_ = [("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double), ("launches", i64), ("busy_ms", C.c_double),
+                ("exec_flops", C.c_double)]
 
 
 K_CLASSES = ("gemm_bf16", "gemm_f32", "attention", "rowops", "rank")

@@ -2,7 +2,8 @@
 """`python -m sprc_amd.cirr_test_submission --blip-model-name blip2_cir_align_prompt --model-path X`
 
 CIRR test1 submission files with the reference's flags and JSON layout (src/cirr_test_submission.py:16-58,
-203-222).  The --rerank branch needs `inference_rerank`, which blip2_cir_align_prompt does not define.
+203-222).  --rerank (the reference's stage-2 branch, :88-112) re-scores every query's top-50 with `inference_rerank`
+(blip2_qformer_cir_rerank.py:399-445: sprc_qformer_encode_kv + sprc_qformer_itm); single-process only.
 """
 from __future__ import annotations
 

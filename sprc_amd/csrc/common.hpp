@@ -31,7 +31,7 @@ void set_error(const char* fmt, ...);
 struct ProfScope {
     int slot;
     hipStream_t st;
-    ProfScope(int cls, hipStream_t stream, double flops, double bytes);
+    ProfScope(int cls, hipStream_t stream, double flops, double bytes, double exec_flops = -1.0);   // exec < 0: == flops
     ~ProfScope();
 };
 

@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---- profiler: event pairs recorded on the launch stream ------------------------------------------
-struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes, exec_flops; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -31,10 +31,10 @@ static hipEvent_t take_event() {
     return e;
 }
 
-ProfScope::ProfScope(int cls, hipStream_t stream, double flops, double bytes) : slot(-1), st(stream) {
+ProfScope::ProfScope(int cls, hipStream_t stream, double flops, double bytes, double exec_flops) : slot(-1), st(stream) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{cls, take_event(), take_event(), flops, bytes};
+    ProfRec r{cls, take_event(), take_event(), flops, bytes, exec_flops < 0.0 ? flops : exec_flops};
     (void)hipEventRecord(r.a, st);
     slot = (int)g_recs.size();
     g_recs.push_back(r);
@@ -61,7 +61,7 @@ extern "C" int sprc_prof_collect(sprc_prof_entry* out) {
     using namespace sprc;
     SPRC_REQUIRE(out != nullptr, "sprc_prof_collect: null output");
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < SPRC_K_COUNT; ++i) out[i] = sprc_prof_entry{0.0, 0.0, 0.0, 0, 0.0};
+    for (int i = 0; i < SPRC_K_COUNT; ++i) out[i] = sprc_prof_entry{0.0, 0.0, 0.0, 0, 0.0, 0.0};
     // launches of one class may overlap in time when the library pipelines two streams: `ms` is the plain sum of launch
     // durations, `busy_ms` the length of the UNION of their [start, end] intervals (time with >= 1 launch of the class
     // executing); on a single stream the two agree.
@@ -71,7 +71,7 @@ extern "C" int sprc_prof_collect(sprc_prof_entry* out) {
         float ms = 0.f, t0 = 0.f;
         (void)hipEventElapsedTime(&ms, r.a, r.b);
         (void)hipEventElapsedTime(&t0, g_recs.front().a, r.a);
-        out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes; out[r.cls].launches += 1;
+        out[r.cls].ms += ms; out[r.cls].flops += r.flops; out[r.cls].bytes += r.bytes; out[r.cls].launches += 1; out[r.cls].exec_flops += r.exec_flops;
         iv[r.cls].push_back({t0, t0 + ms});
     }
     for (int c = 0; c < SPRC_K_COUNT; ++c) {

@@ -73,8 +73,13 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     hipStream_t st = (hipStream_t)s;
     const double osz = a->max32 ? 4.0 / 32.0 : a->out_dtype == SPRC_F16X3 ? 6.0 : (double)dtype_size(a->out_dtype);
     const double np = b != nullptr ? 2.0 : 1.0;
-    ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * a->K,
-                   np * (((double)a->M * a->K + (double)a->N * a->K) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))));
+    // algorithmic work: the product the caller MEANS (k_alg: a split-precision launch reduces over K = 3 k_alg, the patch embedding
+    // over zero padding); executed flops are recorded next to it
+    SPRC_REQUIRE(a->k_alg >= 0 && a->k_alg <= a->K, "sprc_gemm: k_alg=%d outside [0, K=%d]", a->k_alg, a->K);
+    const double ka = a->k_alg > 0 ? (double)a->k_alg : (double)a->K;
+    ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * ka,
+                   np * (((double)a->M * ka + (double)a->N * ka) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))),
+                   np * 2.0 * a->M * (double)a->N * a->K);
     if (a->dtype == SPRC_FP8) return gemm_dispatch_fp8(a, p, st);
     if (a->dtype == SPRC_F16) return gemm_dispatch_f16(a, p, st);
     return a->dtype == SPRC_BF16 ? gemm_dispatch_bf16(a, p, st) : gemm_dispatch_f32(a, p, st);

@@ -28,9 +28,10 @@ struct Fp8Scales { const float* w_scale; float a_scale, out_scale; };
 static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
                 void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0,
                 sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0,
-                const Fp8Scales* q = nullptr, int64_t ldw = 0) {
+                const Fp8Scales* q = nullptr, int64_t ldw = 0, int k_alg = 0) {
     sprc_gemm_args g;
     memset(&g, 0, sizeof(g));
+    g.k_alg = k_alg;
     if (q != nullptr) { g.w_scale = q->w_scale; g.a_scale = q->a_scale; g.out_scale = q->out_scale; }
     g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
     g.A = A; g.lda = lda; g.amap = amap;
@@ -44,10 +45,11 @@ static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const v
 // two products of identical shape in one launch (sprc_gemm_pair): w0 on the rows amap0 -> cmap0, w1 on amap1 -> cmap1
 static int gemm2(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w0,
                  const sprc_linear& w1, void* C, int64_t ldc, int act, const float* resid, int64_t ldr, sprc_rowmap amap0,
-                 sprc_rowmap amap1, sprc_rowmap cmap0, sprc_rowmap cmap1, int64_t ldw = 0) {
+                 sprc_rowmap amap1, sprc_rowmap cmap0, sprc_rowmap cmap1, int64_t ldw = 0, int k_alg = 0) {
     sprc_gemm_args g[2];
     memset(g, 0, sizeof(g));
     for (int i = 0; i < 2; ++i) {
+        g[i].k_alg = k_alg;
         g[i].M = M; g[i].N = N; g[i].K = K; g[i].dtype = dt; g[i].out_dtype = out_dt; g[i].act = act;
         g[i].A = A; g[i].lda = lda; g[i].amap = i ? amap1 : amap0;
         g[i].W = (i ? w1 : w0).w; g[i].ldw = ldw > 0 ? ldw : K; g[i].bias = (i ? w1 : w0).b;
@@ -199,7 +201,7 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
     auto lin = [&](int kind, int rows, int N, int width, const void* in, int64_t lda, const sprc_linear& w, int odt, void* out,
                    int64_t ldc, int act, sprc_rowmap amap, sprc_rowmap cmap) -> int {
         return gemm(st, dt, odt, rows, N, kdim(kind, width), in, lda, w, out, ldc, act, nullptr, 0, amap, cmap, nullptr, 0, nullptr,
-                    wld(kind, width));
+                    wld(kind, width), width);
     };
     // a = LN(dense(in) + res): branch GEMM of layer kind `kind` over `width` input columns, post-LN into (o32, o16)
     auto branch = [&](int kind, int rows, int width, int64_t lda, const void* in, const sprc_linear& w, const float* res,
@@ -209,7 +211,7 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
             return lnorm(st, dt, rows, Hd, res, lw, lb, m->ln_eps, o32, o16, cmap, q.a16);
         }
         RUN(gemm(st, dt, SPRC_F32, rows, Hd, kdim(kind, width), in, lda, w, q.t32, Hd, SPRC_ACT_NONE, res, Hd, amap, cmap, nullptr, 0,
-                 nullptr, wld(kind, width)));
+                 nullptr, wld(kind, width), width));
         return lnorm(st, adt, rows, Hd, q.t32, lw, lb, m->ln_eps, o32, o16, cmap);
     };
     for (int l = 0; l < m->n_layers; ++l) {
@@ -237,7 +239,7 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
                 // 1.4-round grids for the up projection, 90 + 90 instead of two third-empty grids for the down projection.
                 // The hidden activations keep the rows' natural positions in q.ffn [R, F].
                 RUN(gemm2(st, dt, fdt, Rq, F, kdim(SPRC_X3_FFN_IN, Hd), q.a16, KH, L.ffn_q_in, L.ffn_t_in, q.ffn, KF, SPRC_ACT_GELU, nullptr, 0,
-                          qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_IN, Hd)));
+                          qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_IN, Hd), Hd));
                 if (fuse_add) {
                     RUN(gemm2(st, dt, SPRC_F16, Rq, Hd, F, q.ffn, F, L.ffn_q_out, L.ffn_t_out, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, qmap,
                               tmap, qmap, tmap));
@@ -245,7 +247,7 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
                     RUN(lnorm(st, dt, Rq, Hd, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap, q.a16));
                 } else {
                     RUN(gemm2(st, dt, SPRC_F32, Rq, Hd, kdim(SPRC_X3_FFN_OUT, F), q.ffn, KF, L.ffn_q_out, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE,
-                              q.a32, Hd, qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_OUT, F)));
+                              q.a32, Hd, qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_OUT, F), F));
                     RUN(lnorm(st, adt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, qmap));
                     RUN(lnorm(st, adt, Rq, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
                 }
@@ -281,7 +283,7 @@ static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, void* enc16
     }
     const int Nkv = m->n_cross * 2 * m->hidden, Kx = m->enc_width * (kv3 ? 3 : 1);
     return gemm(st, m->dtype, m->dtype, E, Nkv, Kx, enc, Kx, m->ckv_all, kv_out, Nkv, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP, nullptr, 0,
-                nullptr, (int64_t)m->enc_width * ((m->x3 & SPRC_X3_CKV) ? 3 : 1));
+                nullptr, (int64_t)m->enc_width * ((m->x3 & SPRC_X3_CKV) ? 3 : 1), m->enc_width);
 }
 
 // out[rows, embed_dim] (fp32) = proj(hidden rows `amap` of x16): the ITC heads (align_prompt.py:348,385)
@@ -289,7 +291,7 @@ static int head(const sprc_qformer_model* m, hipStream_t st, int cm, int rows, c
                 sprc_rowmap amap) {
     const int Hd = m->hidden;
     return gemm(st, m->dtype, SPRC_F32, rows, m->embed_dim, (cm & SPRC_X3_HEADS) ? 3 * Hd : Hd, x16, x3_layouts(cm).ln ? 3 * Hd : Hd, w, out, m->embed_dim,
-                SPRC_ACT_NONE, nullptr, 0, amap, ID_MAP, nullptr, 0, nullptr, (int64_t)((m->x3 & SPRC_X3_HEADS) ? 3 * Hd : Hd));
+                SPRC_ACT_NONE, nullptr, 0, amap, ID_MAP, nullptr, 0, nullptr, (int64_t)((m->x3 & SPRC_X3_HEADS) ? 3 * Hd : Hd), Hd);
 }
 
 static int check_qf(const sprc_qformer_model* m) {
@@ -341,12 +343,15 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     const size_t pout_bytes = (size_t)P * D * 4;
     const float scale = 1.0f / sqrtf((float)m->head_dim);                       // eva_vit.py:74
     SPRC_REQUIRE(!m->patch_x3 || dt == SPRC_F16, "sprc_vit_forward: patch_x3 is a mode of the fp16 model");
+    const int patch_k = 3 * m->patch_size * m->patch_size;     // the convolution's own reduction length (588; launched zero padded)
     if (m->patch_x3) {                                      // split-precision patch embedding: K' = 3 k_pad, ~fp32 products
         RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, SPRC_F16X3, st));
-        RUN(gemm(st, dt, SPRC_F32, P, D, 3 * m->patch_k_pad, v.rows, 3 * m->patch_k_pad, m->patch, v.pout, D));
+        RUN(gemm(st, dt, SPRC_F32, P, D, 3 * m->patch_k_pad, v.rows, 3 * m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP,
+                 ID_MAP, nullptr, 0, nullptr, 0, patch_k));
     } else {
         RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, dt, st));
-        RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D));
+        RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP,
+                 nullptr, 0, nullptr, 0, patch_k));
     }
     RUN(sprc_vit_assemble(v.pout, m->cls, m->pos, v.x, B, T, D, st));
     if (m->has_ln_pre) RUN(lnorm(st, dt, M, D, v.x, m->ln_pre_w, m->ln_pre_b, m->ln_eps, v.x, nullptr));

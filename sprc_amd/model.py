@@ -15,8 +15,8 @@ Deliberate differences from the reference (documented in DESIGN.md):
   * eval semantics always (dropout = identity).  The reference's CIRR scripts leave the Q-Former in
     train mode, which makes their features stochastic.
   * `inference` always returns a 2-D [B,N] tensor (the reference's `.squeeze()` collapses B=1 / N=1).
-  * `forward` (the three training losses, align_prompt.py:95-200) is forward-only: values match the reference in eval
-    mode, but there are no backward kernels.
+  * `forward` (the three training losses, align_prompt.py:95-200) carries autograd history: its backward runs the HIP backward
+    kernels (sprc_amd/train.py, csrc/train.hip), so the reference's training loop runs against this class.
 """
 from __future__ import annotations
 
@@ -88,7 +88,7 @@ class Blip2QformerCirAlignPrompt(nn.Module):
             params = dict(self.named_parameters())
             for name, t in synth.iter_state_dict(self.cfg, seed, device=gen_dev):
                 params[name].copy_(t)
-        self._engine = None
+        self._drop_engines()
         return self
 
     # ---- nn.Module plumbing ---------------------------------------------------------------------
@@ -96,12 +96,18 @@ class Blip2QformerCirAlignPrompt(nn.Module):
     def device(self) -> torch.device:
         return list(self.parameters())[0].device                 # base_model.py:25-27
 
-    def load_state_dict(self, state_dict, strict: bool = True):
+    def _drop_engines(self) -> None:
+        """Both packed engines are snapshots of the parameters: the inference engine AND the frozen trunk of the training step
+        (`_train_engine`) are rebuilt after anything that replaces or moves the weights."""
         self._engine = None
+        self._tengine = None
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        self._drop_engines()
         return super().load_state_dict(state_dict, strict=strict)
 
     def _apply(self, fn, *a, **k):
-        self._engine = None
+        self._drop_engines()
         return super()._apply(fn, *a, **k)
 
     def train(self, mode: bool = True):
@@ -257,6 +263,17 @@ class Blip2QformerCirRerank(Blip2QformerCirAlignPrompt):
     @torch.no_grad()
     def fuse(self, reference_embeds, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         return self.engine().qformer_text(input_ids, attention_mask)      # reference_embeds unused, as in the reference (:373-390)
+
+    def forward(self, samples):
+        """The rerank class trains a DIFFERENT objective in the reference (blip2_qformer_cir_rerank.py:100-371: ITM over hard negatives
+        mined with its frozen Fformer copy; itm_head receives the gradient) -- not built here.  Inheriting align_prompt's
+        differentiable forward would silently train the wrong losses, so a call with autograd enabled is refused; under
+        torch.no_grad() the align_prompt losses are still available as a diagnostic."""
+        if torch.is_grad_enabled():
+            raise NotImplementedError("Blip2QformerCirRerank.forward: the stage-2 training objective (ITM with the frozen Fformer, "
+                                      "blip2_qformer_cir_rerank.py:100-371) is not implemented; train stage 1 with "
+                                      "blip2_cir_align_prompt, or call under torch.no_grad()")
+        return super().forward(samples)
 
 
 _MODEL_REGISTRY: Dict[str, type] = {"blip2_cir_align_prompt": Blip2QformerCirAlignPrompt,

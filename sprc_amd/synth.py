@@ -165,14 +165,37 @@ def plant_structure(sd: Dict[str, torch.Tensor], seed: int = 0) -> Dict[str, tor
     return sd
 
 
-def make_state_dict(cfg: SprcConfig, seed: int = 0, device: str = "cpu", planted: bool = False) -> Dict[str, torch.Tensor]:
-    """Seeded random state dict with the reference's key names (fp32); planted=True: see `plant_structure`."""
+# tensors of the trunk that the reference's convert_weights_to_fp16 (eva_vit.py:410-425; clip_vit.py:12 imports the same function)
+# turns into fp16: weight and bias of every nn.Conv2d / nn.Linear MODULE.  EVA's q_bias / v_bias and nn.MultiheadAttention's
+# in_proj_* are bare Parameters and stay fp32, like cls / pos embeddings and the LayerNorms.
+_TRUNK_FP16_SUFFIXES = ("patch_embed.proj.weight", "patch_embed.proj.bias", "attn.qkv.weight", "attn.proj.weight", "attn.proj.bias",
+                        "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias",
+                        "conv1.weight", "attn.out_proj.weight", "attn.out_proj.bias", "mlp.c_fc.weight", "mlp.c_fc.bias",
+                        "mlp.c_proj.weight", "mlp.c_proj.bias")
+
+
+def round_trunk_to_fp16(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The state dict as a GPU-trained reference checkpoint holds it ("ViT Linear/Conv weights are fp16 in
+    GPU-trained checkpoints"; the released SPRC checkpoint is the full state_dict() of a model built with vit_precision="fp16",
+    README.md:123-128, utils.py:219-222): the trunk's Conv / Linear tensors take fp16 VALUES (kept as fp32 tensors here, which is
+    what the reference's CPU path makes of them: models/__init__.py:246-247 `model.float()`).  In place."""
+    for k in sd:
+        if k.startswith("visual_encoder.") and k.endswith(_TRUNK_FP16_SUFFIXES):
+            sd[k] = sd[k].to(torch.float16).to(torch.float32)
+    return sd
+
+
+def make_state_dict(cfg: SprcConfig, seed: int = 0, device: str = "cpu", planted: bool = False, trunk_fp16: bool = False) -> Dict[str, torch.Tensor]:
+    """Seeded random state dict with the reference's key names (fp32); planted=True: see `plant_structure`; trunk_fp16=True:
+    the trunk's Conv / Linear tensors hold fp16-representable values, as in a GPU-trained checkpoint (`round_trunk_to_fp16`)."""
     sd = dict(iter_state_dict(cfg, seed, device))
     sd["temp"] = torch.tensor(0.07, device=device)          # align_prompt.py:84 (unused by inference)
     if planted:
         if device != "cpu":
             raise ValueError("planted weights are drawn on the CPU (reproducible against the golden fixtures)")
         plant_structure(sd, seed)
+    if trunk_fp16:
+        round_trunk_to_fp16(sd)
     return sd
 
 

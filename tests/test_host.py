@@ -111,6 +111,23 @@ def test_model_surface_and_checkpoint_keys():
         load_model_and_preprocess("blip2_cir_rerank_learn", "pretrain")
 
 
+def test_engine_snapshots_are_dropped_when_the_weights_change():
+    """the training step's frozen-trunk engine (`_tengine`) is a snapshot of the parameters exactly like the inference
+    engine -- load_state_dict / .to() / init_synthetic must drop BOTH, or a later training step runs a stale trunk."""
+    from sprc_amd.config import get_config
+    from sprc_amd.model import Blip2QformerCirAlignPrompt, Blip2QformerCirRerank
+    cfg = get_config("pretrain", vit_depth=1, q_layers=1)
+    m = Blip2QformerCirAlignPrompt(cfg=cfg)
+    for op in (lambda: m.load_state_dict(m.state_dict()), lambda: m.to(torch.float32), lambda: m.init_synthetic(1)):
+        m._engine, m._tengine = object(), object()
+        op()
+        assert m._engine is None and m._tengine is None
+    # the rerank class must not inherit align_prompt's differentiable forward (its reference objective is a different one)
+    r = Blip2QformerCirRerank(cfg=cfg)
+    with pytest.raises(NotImplementedError, match="stage-2 training objective"):
+        r({"image": torch.zeros(1, 3, 224, 224), "target": torch.zeros(1, 3, 224, 224), "text_input": ["x"]})
+
+
 def test_synthetic_inputs_follow_the_measurement_contract():
     from sprc_amd import synth
     ids, mask, ref = synth.make_queries(50, 97, seed=1)
