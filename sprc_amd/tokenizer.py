@@ -8,11 +8,14 @@ path (``vocab.txt`` of bert-base-uncased) via ``SPRC_BERT_VOCAB`` or the constru
 algorithm below is the published BERT one (basic tokenisation: clean, lower-case, NFD accent
 strip, punctuation split, CJK isolation; then greedy longest-match-first WordPiece with "##"
 continuation, 100-char word cap) and is checked against the installed `transformers`
-implementation on synthetic vocabularies in tests/test_host.py.
+implementation on synthetic vocabularies in tests/test_host.py and fuzzed against it in
+tests/test_tokenizer_fuzz.py (10 k random strings over three synthetic vocabularies; the real
+vocabulary too when SPRC_BERT_VOCAB is set).
 """
 from __future__ import annotations
 
 import os
+import re
 import unicodedata
 from typing import Dict, List, Sequence
 
@@ -65,6 +68,9 @@ class BertWordPieceTokenizer:
         self.do_lower_case = do_lower_case
         self.unk, self.cls, self.sep, self.pad = (self.vocab[t] for t in ("[UNK]", "[CLS]", "[SEP]", "[PAD]"))
         self.never_split = {"[UNK]", "[CLS]", "[SEP]", "[PAD]", "[MASK]", *extra_special}
+        # special-token literals are cut out of the RAW text before any normalisation (transformers: the added-tokens trie of
+        # PreTrainedTokenizer.tokenize / the AddedVocabulary of the fast tokenizers): "x[MASK]y" -> "x", [MASK], "y"; case-sensitive
+        self._special_re = re.compile("(" + "|".join(re.escape(t) for t in sorted(self.never_split, key=len, reverse=True)) + ")")
 
     def __len__(self) -> int:
         return len(self.vocab)
@@ -83,9 +89,6 @@ class BertWordPieceTokenizer:
         text = unicodedata.normalize("NFC", "".join(out))
         words: List[str] = []
         for tok in text.strip().split():
-            if tok in self.never_split:
-                words.append(tok)
-                continue
             if self.do_lower_case:
                 tok = tok.lower()
                 tok = "".join(c for c in unicodedata.normalize("NFD", tok) if unicodedata.category(c) != "Mn")
@@ -124,8 +127,12 @@ class BertWordPieceTokenizer:
 
     def encode(self, text: str, max_length: int) -> List[int]:
         ids: List[int] = []
-        for w in self._basic(text):
-            ids.extend([self.vocab[w]] if w in self.never_split else self._wordpiece(w))
+        for i, seg in enumerate(self._special_re.split(text)):
+            if i % 2 == 1:                                   # a special-token literal
+                ids.append(self.vocab[seg])
+                continue
+            for w in self._basic(seg):
+                ids.extend(self._wordpiece(w))
         ids = ids[: max_length - 2]                      # truncation=True, truncation_side="right"
         return [self.cls] + ids + [self.sep]
 
