@@ -78,6 +78,9 @@ def parse():
     ap.add_argument("--qf-streams", type=int, default=2, help="2 = the gallery-side and the query-side Q-Former passes of a step run on two streams")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = batch i's Q-Former passes and ranking overlap batch i+1's ViT (side streams, raw embeddings "
                     "double-buffered); instrumented steps (--prof-every) stay serialised")
+    ap.add_argument("--recall", action="store_true", help="after the timed region: Recall@1/5/10/50 + subset recalls of the benchmarked engine on the "
+                    "planted-structure CIRR-val-sized case (2297 images x 4181 queries, sprc_amd/planted.py) next to the exact-fp32 engine's on the "
+                    "same targets -> a `recall` object in the line (~1 min; synthetic weights: the real checkpoint is a network fetch)")
     ap.add_argument("--cpu-images", type=int, default=32, help="size of the bounded CPU-baseline sample (~15 s of CPU work on 16 cores)")
     return ap.parse_args()
 
@@ -249,6 +252,13 @@ def main():
         else:
             dist.init_process_group("gloo")
         assert dist.get_world_size() == a.gpus
+        if backend == "nccl":
+            # one rank per DEVICE over RCCL, or the line is not a scaling number: every rank reports its device index and bus id
+            assert dist.get_backend() == "nccl"
+            mine = (torch.cuda.current_device(), str(getattr(torch.cuda.get_device_properties(dev), "uuid", local)))
+            seen = [None] * world
+            dist.all_gather_object(seen, mine)
+            assert len(set(seen)) == world, f"bench.py --gpus {a.gpus}: ranks share devices under the nccl backend: {seen}"
 
     from sprc_amd import _lib as L
     from sprc_amd import engine as E
@@ -374,7 +384,12 @@ def main():
     prof = (L.ProfEntry * len(L.K_CLASSES))()
     L.check(lib.sprc_prof_collect(prof), "sprc_prof_collect")
     lib.sprc_prof_enable(0)
+    per_rank_ms = [round(dt / a.steps * 1e3, 3)]
     if world > 1:
+        # value uses the MAX over ranks (the contract); every rank's own step time rides along so that a straggler shows in the record
+        times = [None] * world
+        torch.distributed.all_gather_object(times, dt)
+        per_rank_ms = [round(float(x) / a.steps * 1e3, 3) for x in times]
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -425,6 +440,7 @@ def main():
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
                        "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_streams": a.qf_streams, "pipeline": int(bool(a.pipeline)),
                        "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and backend == "nccl" else None),
+                       "per_rank_ms_per_step": per_rank_ms,
                        "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if world > 1 else None},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNELS[a.dtype], "achieved": round(ach, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -444,6 +460,22 @@ def main():
                          "executed_tflops": round(pe.exec_flops / max(pe.busy_ms, 1e-9) / 1e9, 1)},
             "kernels": kernels,
         }
+        if a.recall and a.backbone == "pretrain" and a.dtype in ("fp16", "bf16", "fp32"):
+            # BASELINE.json's metric names Recall@K next to the throughput: measured on planted-structure weights / images at CIRR-val's
+            # sizes, targets at planned ranks of the exact-fp32 engine's ordering (the fp32 engine is within 5e-6 of the reference's scores
+            # on every reference-generated golden, incl. 438 727 scores of this very case: tests/test_configs_gpu.py)
+            from sprc_amd import planted as P
+            del eng
+            torch.cuda.empty_cache()
+            sdp = synth.make_state_dict(cfg, seed=5, planted=True)
+            s_ref, refq = P.planted_scores(cfg, sdp, dev, "fp32")
+            s_eng, _ = P.planted_scores(cfg, sdp, dev, a.dtype)
+            rep = P.recall_report(s_ref, s_eng, refq)
+            out["recall"] = {"engine": rep["engine"], "fp32_engine_as_reference": rep["reference_order"],
+                             "equal_recall_at_1_5_10": all(rep["engine"][k] == rep["reference_order"][k] for k in ("recall_at_1", "recall_at_5", "recall_at_10")),
+                             "max_abs_dsim": rep["max_abs_dsim"], "rms_dsim": rep["rms_dsim"], "top1_image_equal_pct": rep["top1_image_equal_pct"],
+                             "case": f"planted-structure synthetic weights and images, {P.N_GALLERY} gallery x {P.N_QUERIES} queries (CIRR-val sizes), full depth, "
+                                     f"engine dtype {a.dtype}; targets at planned ranks of the fp32 engine's ordering"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_images)
         print(json.dumps(out), flush=True)

@@ -37,12 +37,18 @@ enum { SPRC_F32 = 0, SPRC_BF16 = 1,
                        lavis/models/blip2_models/blip2.py:36-44, eva_vit.py:410-425), 8x finer operand rounding than bf16.
                        Also an OUTPUT dtype of a bf16 sprc_gemm: a residual-branch output ("delta") that sprc_layernorm
                        adds to the fp32 residual stream */,
-       SPRC_F16X3 = 4 /* STORAGE layout of split-precision fp16 activations (OUTPUT dtype of sprc_gemm / sprc_layernorm /
-                         sprc_qformer_embed / sprc_cast_f32_to_16 / sprc_attention.out_x3): a logical [M, K] matrix x is stored as
-                         [M, 3K] fp16 = [hi | lo | hi] with hi = fp16(x), lo = fp16(x - hi).  Multiplied (plain SPRC_F16 sprc_gemm,
-                         K' = 3K) with weights packed [W_hi | W_hi | W_lo] it yields x_hi.W_hi + x_lo.W_hi + x_hi.W_lo: the product
-                         to ~2^-21 instead of 2^-11 -- what lets the Q-Former of the fp16 engine follow the reference's GPU path,
-                         whose Q-Former runs in fp32 OUTSIDE the fp16 autocast (blip2_qformer_cir_align_prompt.py:366-368) */,
+       SPRC_F16X3 = 4 /* STORAGE layout of split-precision activations (OUTPUT dtype of sprc_gemm / sprc_layernorm / sprc_qformer_embed /
+                         sprc_cast_f32_to_x3 / sprc_im2row / sprc_attention.out_x3): a row of a logical [M, K] matrix x takes 4K bytes,
+                             [ K x fp16: hi = fp16(x) | K x e4m3: (x - hi) * 2^12 | K x e4m3: x ]
+                         (ABI 4; ABI 3 stored three fp16 segments [hi | lo | hi]).  A split product -- sprc_gemm with dtype SPRC_F16,
+                         K, and k8 = 2K -- multiplies it with weight rows [ K x fp16: W_hi | K x e4m3: W * 2^6 | K x e4m3: (W - W_hi) * 2^18 ]:
+                             x_hi.W_hi  +  2^-18 ( [x_lo 2^12].[W 2^6] + [x].[W_lo 2^18] )   =   x.W  up to the e4m3 rounding of the two
+                         CORRECTION terms, which are 2^-11 of the result and need 3-4 significant bits: the product to ~2^-16 instead of
+                         2^-11 (measured: relative rms error 1.0e-5 against 2.9e-4 for plain fp16 and 9e-7 for three fp16 segments),
+                         at 2 units of matrix time instead of 3 -- the e4m3 K-tiles run on the MX-scaled MFMA at twice the fp16 rate
+                         (block scales 2^-9 x 2^-9).  This is what lets the Q-Former of the fp16 engine follow the reference's GPU
+                         path, whose Q-Former runs in fp32 OUTSIDE the fp16 autocast (blip2_qformer_cir_align_prompt.py:366-368).
+                         A consumer that is not split reads the hi segment alone (K fp16, leading dimension 2K). */,
        SPRC_FP8 = 3 /* OCP e4m3fn (the gfx950 fp8; NOT MI300's fnuz): GEMM operands with a per-tensor activation scale and
                        per-output-channel weight scales, fp32 accumulation (BASELINE.json config C5: "ViT-L, fp8 MFMA") */ };
 enum { SPRC_ACT_NONE = 0, SPRC_ACT_GELU = 1, SPRC_ACT_QUICKGELU = 2 };
@@ -86,14 +92,14 @@ int sprc_absmax_16(const void* x, size_t n, int32_t dtype, float* amax, sprc_str
 int sprc_cast_f32_to_bf16(const float* src, uint16_t* dst, size_t n, sprc_stream s);
 /* fp32 -> `dtype` (SPRC_BF16 or SPRC_F16), round-to-nearest-even. */
 int sprc_cast_f32_to_16(const float* src, void* dst, size_t n, int32_t dtype, sprc_stream s);
-/* fp32 [rows, cols] (contiguous) -> SPRC_F16X3 [rows, 3 cols]; cols % 4 == 0. */
+/* fp32 [rows, cols] (contiguous) -> SPRC_F16X3 rows (4 cols bytes each, contiguous); cols % 4 == 0. */
 int sprc_cast_f32_to_x3(const float* src, void* dst, int64_t rows, int32_t cols, sprc_stream s);
 
 /* C = epilogue(A[M,K] . W[N,K]^T + bias) -- replaces every nn.Linear / F.linear on the path:
  * eva_vit.py:123,146,55-60; clip_vit.py:132-139; Qformer.py:135-137,201-211,291-293,365,377;
  * align_prompt.py:348,385.  A and W are `dtype`; bias/resid fp32; out is `out_dtype`.
  * K % 64 == 0 (bf16, fp16) / K % 32 == 0 (f32); lda, ldw multiples of 8 (16-bit) / 4 (f32) elements.
- * dtype SPRC_F16: outputs fp16, f32 or SPRC_F16X3 (ldc >= 3 N, N % 4 == 0; no residual, no max32), every activation.
+ * dtype SPRC_F16: outputs fp16, f32 or SPRC_F16X3 (ldc >= 2 N in fp16 units, N % 4 == 0; no residual, no max32), every activation.
  * out_dtype SPRC_F16 with bf16 operands: no activation / residual / max32 (see sprc_layernorm_args.add16).
  * dtype SPRC_FP8: K % 128 == 0; outputs bf16 / fp16 / f32 (plain epilogue, residual allowed) or fp8 (any activation).
  *   out = act(A.W^T + bias) + resid                         (resid optional, fp32, mapped like C)
@@ -118,6 +124,11 @@ typedef struct {
      * A split-precision product over [hi | lo | hi] . [W_hi | W_hi | W_lo] launches K = 3 k_alg; the patch embedding launches its
      * zero-padded K (640 for 588).  Never changes what is computed. */
     int32_t k_alg;
+    /* ABI 4, dtype SPRC_F16 only: split-precision product.  Every row of A and W holds K fp16 elements FOLLOWED by k8 e4m3fn elements
+     * (k8 == 2K: the SPRC_F16X3 layout above; lda / ldw in fp16 units >= K + k8 / 2); out = epilogue(sum over the fp16 part +
+     * 2^-18 * sum over the e4m3 part).  K % 128 == 0, k8 % 128 == 0, k8 >= 512.  0 = a plain product.  Epilogues: bias, GELU,
+     * fp32 residual; outputs SPRC_F16 / SPRC_F32 / SPRC_F16X3; sprc_gemm_pair allowed; no max32. */
+    int32_t k8;
 } sprc_gemm_args;
 int sprc_gemm(const sprc_gemm_args* a, sprc_stream s);
 
@@ -136,7 +147,7 @@ typedef struct {
     const float* x;  int64_t ldx;  sprc_rowmap xmap;
     const float* gamma; const float* beta; float eps;
     float* y32;      int64_t ld32; sprc_rowmap ymap;
-    void*  y16;      int64_t ld16;              /* rows mapped with ymap as well; out_dtype SPRC_F16X3: ld16 >= 3 D */
+    void*  y16;      int64_t ld16;              /* rows mapped with ymap as well; out_dtype SPRC_F16X3: ld16 >= 2 D (fp16 units; a split row is 4 D bytes) */
     /* Optional fused residual add (bf16 engine): the normalised row is x + add16, with add16 the fp16 output of the branch
      * GEMM (attention proj / MLP fc2 / BERT output.dense: eva_vit.py:178-179, clip_vit.py:137-138, Qformer.py:294,380).
      * The fp32 + residual GEMM epilogue it replaces was an un-overlapped HBM burst (8 B per element with the matrix pipe
@@ -172,13 +183,13 @@ typedef struct {
     const void* v2; int64_t ldv2;
     int32_t Tk2;
     const int32_t* kv_index; const int32_t* kv2_index;
-    int32_t out_x3;   /* dtype SPRC_F16 only: `out` is stored in the SPRC_F16X3 layout (logical width H * head_dim, ldo >= 3 H head_dim) */
+    int32_t out_x3;   /* dtype SPRC_F16 only: `out` rows are stored in the SPRC_F16X3 layout (logical width H * head_dim, ldo >= 2 H head_dim) */
 } sprc_attention_args;
 int sprc_attention(const sprc_attention_args* a, sprc_stream s);
 
 /* Patch extraction for the 14x14/stride-14 conv (eva_vit.py:196,203; clip_vit.py:160,173-175):
  * images [B,3,S,S] fp32 -> rows [B*G*G, k_pad] (`dtype`), column = c*P*P + i*P + j, zero padded.
- * dtype SPRC_F16X3: rows [B*G*G, 3 k_pad] = [hi | lo | hi] (fp16). */
+ * dtype SPRC_F16X3: split rows of logical width k_pad (4 k_pad bytes each). */
 int sprc_im2row(const float* images, void* rows, int32_t B, int32_t image, int32_t patch, int32_t k_pad,
                 int32_t dtype, sprc_stream s);
 
@@ -196,7 +207,7 @@ typedef struct {
     const int64_t* input_ids;
     const float* word_emb; const float* pos_emb;
     const float* gamma; const float* beta; float eps;
-    float* y32; void* y16;                      /* [B, Lq+Lt, hidden] contiguous ([.., 3 hidden] for out_dtype SPRC_F16X3) */
+    float* y32; void* y16;                      /* [B, Lq+Lt, hidden] contiguous (split rows of 4 hidden bytes for out_dtype SPRC_F16X3) */
     int32_t no_img;                             /* 1: the text-only form of Qformer.py:88-104 (training, align_prompt.py:173-179): rows =
                                                  * [text[0] ; the Lq query rows ; text[1:]] and every row gets its absolute position */
 } sprc_qformer_embed_args;
@@ -264,8 +275,8 @@ typedef struct {
                                                  * fc2 inputs, updated by sprc_vit_forward -- the calibration pass of the fp8 scales */
     float* pre_ln_out;                          /* optional device array [B, tokens, width] fp32: receives the INPUT of ln_vision (the ViT's last
                                                  * residual stream) -- what the training step needs for ln_vision's gradient (blip2.py:81) */
-    int32_t patch_x3;                           /* dtype SPRC_F16 only, 1: the patch embedding runs on split-precision operands -- patch.w is
-                                                 * [W_hi | W_hi | W_lo], [width, 3 patch_k_pad], the patch rows are SPRC_F16X3.  Its output IS the
+    int32_t patch_x3;                           /* dtype SPRC_F16 only, 1: the patch embedding runs on split-precision operands -- patch.w holds
+                                                 * split weight rows [W_hi | W 2^6 | W_lo 2^18] (4 patch_k_pad bytes each), the patch rows are SPRC_F16X3.  Its output IS the
                                                  * residual stream's first value: an fp16 rounding there is carried through every block
                                                  * (tools/fq_vit.py: 27 % of the fp16 ViT's error variance, for 0.1 ms) */
 } sprc_vit_model;
@@ -288,9 +299,9 @@ typedef struct {
     const sprc_qf_layer* layers;                /* host array [n_layers] */
     int32_t x3;                                 /* != 0 (dtype SPRC_F16 only): split-precision Q-Former -- every GEMM input activation is
                                                  * kept in the SPRC_F16X3 layout, and the weight matrices of the layer KINDS whose SPRC_X3_*
-                                                 * bit is set are packed [out, 3 in] = [W_hi | W_hi | W_lo] (the others stay [out, in] and
-                                                 * multiply the hi segment only); attention operands (q, k, v, probabilities) stay plain fp16 */
-    int32_t x3_image, x3_fuse;                  /* subsets of x3: the kinds that reduce over all three segments in sprc_qformer_image /
+                                                 * bit is set are packed as split weight rows [W_hi fp16 | W 2^6 e4m3 | W_lo 2^18 e4m3], 4 `in` bytes each
+                                                 * (the others stay [out, in] fp16 and multiply the hi segment only); attention operands (q, k, v, probabilities) stay plain fp16 */
+    int32_t x3_image, x3_fuse;                  /* subsets of x3: the kinds that run the split product (k8 = 2 K) in sprc_qformer_image /
                                                  * in the query-side calls (fuse, text_only, encode_kv, itm); the others read hi only */
 } sprc_qformer_model;
 

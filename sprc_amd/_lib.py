@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
                 ("A", vp), ("lda", i64), ("amap", RowMap), ("W", vp), ("ldw", i64), ("bias", vp),
                 ("resid", vp), ("ldr", i64), ("C", vp), ("ldc", i64), ("cmap", RowMap),
                 ("scratch", vp), ("scratch_bytes", C.c_size_t), ("w_scale", vp), ("a_scale", f32), ("out_scale", f32),
-                ("k_alg", i32)]
+                ("k_alg", i32), ("k8", i32)]
 
 
 class LayerNormArgs(C.Structure):

@@ -9,7 +9,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libsprc_hip.so"
-SOURCES = ["gemm.hip", "gemm_f16.hip", "gemm_fp8.hip", "gemm_f32.hip", "core.hip", "attention.hip", "rowops.hip", "rank.hip", "models.hip", "preprocess.hip", "train.hip"]
+SOURCES = ["gemm.hip", "gemm_f16.hip", "gemm_f16e.hip", "gemm_fp8.hip", "gemm_f32.hip", "core.hip", "attention.hip", "rowops.hip", "rank.hip", "models.hip", "preprocess.hip", "train.hip"]
 # -fno-slp-vectorize: hipcc packs adjacent scalar fp32 ops into v_pk_fma_f32 / v_pk_mul_f32, which run SLOWER than the scalar
 # pairs on gfx950 (measured on the GEMM GELU epilogue: 117 us packed vs ~45 us scalar per ViT fc1 launch)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = True, always: tuple = ()) -> Path
             subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(11, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     # (build.py itself is a dependency: the source LIST lives here -- a new translation unit must relink)
     if force or _stale(LIB, [*objs, Path(__file__)]):

@@ -55,7 +55,7 @@ struct AttnParams {
     const char* k2; int64_t ldk2;
     const char* v2; int64_t ldv2;
     const int32_t* idx1; const int32_t* idx2;
-    int x3;                         // > 0 (fp16, resident kernel): `out` in the SPRC_F16X3 layout, x3 = logical row width H * dh
+    int x3;                         // > 0 (fp16, resident kernel): `out` rows in the SPRC_F16X3 layout, x3 = logical row width H * dh
 };
 
 // byte address of head h of key/value token t of batch b (t in the concatenated key axis)
@@ -260,12 +260,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bf16_kernel(AttnParams p) {
                     const int d0 = dt * 32 + 8 * g + 4 * half;
                     if (d0 < dh) {
                         if constexpr (F16) {
-                            if (p.x3 > 0) {             // split-precision output: [hi | lo | hi], lo = fp16(x - hi)
-                                f16x4 hi, lo;
-                                split_f16x4(o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv, o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv, hi, lo);
-                                *reinterpret_cast<f16x4*>(optr + d0 * 2) = hi;
-                                *reinterpret_cast<f16x4*>(optr + (p.x3 + d0) * 2) = lo;
-                                *reinterpret_cast<f16x4*>(optr + (2 * p.x3 + d0) * 2) = hi;
+                            if (p.x3 > 0) {             // split-precision output row (SPRC_F16X3): [hi fp16 | lo e4m3 | hi e4m3], logical width p.x3
+                                store_split4(optr - (int64_t)h * dh * 2, p.x3, h * dh + d0, o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv,
+                                             o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
                                 continue;
                             }
                         }
@@ -1042,8 +1039,8 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
                  (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale,
                  a->Tk, (const char*)a->k2, a->ldk2, (const char*)a->v2, a->ldv2, a->kv_index, a->kv2_index,
                  a->out_x3 ? a->H * a->head_dim : 0};
-    SPRC_REQUIRE(!a->out_x3 || (a->dtype == SPRC_F16 && a->Tq <= 128 && a->ldo >= 3 * (int64_t)a->H * a->head_dim && (a->H * a->head_dim) % 4 == 0),
-                 "sprc_attention: out_x3 needs dtype SPRC_F16, Tq <= 128 (resident kernel), ldo >= 3 H head_dim");
+    SPRC_REQUIRE(!a->out_x3 || (a->dtype == SPRC_F16 && a->Tq <= 128 && a->ldo >= 2 * (int64_t)a->H * a->head_dim && (a->H * a->head_dim) % 4 == 0),
+                 "sprc_attention: out_x3 needs dtype SPRC_F16, Tq <= 128 (resident kernel), ldo >= 2 H head_dim (a split row is 4 bytes per column)");
     hipStream_t st = (hipStream_t)s;
     const double bh = (double)a->B * a->H, esz = (double)dtype_size(a->dtype);
     ProfScope prof(SPRC_K_ATTN, st, 4.0 * bh * a->Tq * (double)Tk_all * a->head_dim,

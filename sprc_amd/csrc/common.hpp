@@ -73,6 +73,40 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
+// ---- SPRC_F16X3: the split-precision row [K fp16: hi = fp16(x) | K e4m3: (x - hi) 2^12 | K e4m3: x]  (sprc.h) -----------------------
+// saturating fp32 -> 4 x e4m3fn (v_cvt_pk_fp8_f32: RNE; inputs clamped to +-448 first, the format has no infinity)
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, lo, true);
+}
+constexpr float SPLIT_LO_SCALE = 4096.0f;        // 2^12: an fp16 rounding residual (<= 2^-11 |x|) lands in e4m3's normal range for |x| in [2^-6, 2^8]
+// hi = fp16(x) and the EXACT residual x - hi (fp32); x is pinned first for the reason given at split_f16
+__device__ __forceinline__ void split_f16_res(float x, _Float16& hi, float& res) {
+    asm("" : "+v"(x));
+    hi = (_Float16)x;
+    res = x - (float)hi;
+}
+// four consecutive columns [col, col + 4) of a split row of logical width K; `row` = first byte of the row; col % 4 == 0
+__device__ __forceinline__ void store_split4(char* row, int K, int col, float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+    _Float16 h0, h1, h2, h3;
+    float r0, r1, r2, r3;
+    split_f16_res(a, h0, r0); split_f16_res(b, h1, r1); split_f16_res(c, h2, r2); split_f16_res(d, h3, r3);
+    *reinterpret_cast<half4*>(row + 2 * col) = half4{h0, h1, h2, h3};
+    *reinterpret_cast<uint32_t*>(row + 2 * K + col) = pack_fp8x4(r0 * SPLIT_LO_SCALE, r1 * SPLIT_LO_SCALE, r2 * SPLIT_LO_SCALE, r3 * SPLIT_LO_SCALE);
+    *reinterpret_cast<uint32_t*>(row + 3 * K + col) = pack_fp8x4(a, b, c, d);
+}
+__device__ __forceinline__ void store_split1(char* row, int K, int col, float x) {
+    _Float16 h;
+    float r;
+    split_f16_res(x, h, r);
+    *reinterpret_cast<_Float16*>(row + 2 * col) = h;
+    *reinterpret_cast<uint8_t*>(row + 2 * K + col) = (uint8_t)(pack_fp8x4(r * SPLIT_LO_SCALE, 0.f, 0.f, 0.f) & 0xffu);
+    *reinterpret_cast<uint8_t*>(row + 3 * K + col) = (uint8_t)(pack_fp8x4(x, 0.f, 0.f, 0.f) & 0xffu);
+}
+
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 __device__ __forceinline__ void split_f16x4(float a, float b, float c, float d, f16x4& hi, f16x4& lo) {
     _Float16 h0, h1, h2, h3, l0, l1, l2, l3;

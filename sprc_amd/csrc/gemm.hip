@@ -14,8 +14,11 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     SPRC_REQUIRE(a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F32 || a->out_dtype == SPRC_F16 || a->out_dtype == SPRC_FP8 ||
                      a->out_dtype == SPRC_F16X3, "sprc_gemm: bad out_dtype %d", a->out_dtype);
     SPRC_REQUIRE(a->out_dtype != SPRC_F16X3 || (a->dtype == SPRC_F16 && !a->resid && !a->max32 && a->act != SPRC_ACT_QUICKGELU &&
-                                                a->N % 4 == 0 && a->ldc >= 3 * (int64_t)a->N),
-                 "sprc_gemm: SPRC_F16X3 output takes fp16 operands, N %% 4 == 0, ldc >= 3 N, no residual / max32 / QuickGELU");
+                                                a->N % 4 == 0 && a->ldc >= 2 * (int64_t)a->N),
+                 "sprc_gemm: SPRC_F16X3 output takes fp16 operands, N %% 4 == 0, ldc >= 2 N (fp16 units), no residual / max32 / QuickGELU");
+    SPRC_REQUIRE(a->k8 >= 0 && (a->k8 == 0 || (a->dtype == SPRC_F16 && !a->max32 && a->K % 128 == 0 && a->k8 % 128 == 0 && a->k8 >= 512 &&
+                                               a->lda >= a->K + a->k8 / 2 && a->ldw >= a->K + a->k8 / 2)),
+                 "sprc_gemm(k8): a split-precision product takes fp16 operands, K %% 128 == 0, k8 %% 128 == 0, k8 >= 512, lda / ldw >= K + k8 / 2, no max32");
     SPRC_REQUIRE(a->dtype != SPRC_FP8 || (a->w_scale != nullptr && a->a_scale > 0.f && !a->max32 && b == nullptr),
                  "sprc_gemm(fp8): needs w_scale, a_scale > 0; no max32 / paired launch");
     SPRC_REQUIRE(a->out_dtype != SPRC_FP8 || a->out_scale > 0.f, "sprc_gemm: SPRC_FP8 output needs out_scale > 0");
@@ -54,7 +57,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     if (b != nullptr) {                 // second product of a paired launch: same shapes, operands A / C / resid and row-map geometry
         SPRC_REQUIRE(!a->max32 && !b->max32, "sprc_gemm_pair: no max32 epilogue");
         SPRC_REQUIRE(b->M == a->M && b->N == a->N && b->K == a->K && b->dtype == a->dtype && b->out_dtype == a->out_dtype &&
-                         b->act == a->act && b->A == a->A && b->lda == a->lda && b->ldw == a->ldw && b->C == a->C &&
+                         b->act == a->act && b->A == a->A && b->lda == a->lda && b->ldw == a->ldw && b->C == a->C && b->k8 == a->k8 &&
                          b->ldc == a->ldc && b->resid == a->resid && b->ldr == a->ldr &&
                          b->amap.rows_per_group == a->amap.rows_per_group && b->amap.group_stride == a->amap.group_stride &&
                          b->cmap.rows_per_group == a->cmap.rows_per_group && b->cmap.group_stride == a->cmap.group_stride,
@@ -70,6 +73,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
     p.debug = dbg;
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
+    p.k8 = a->k8;
     hipStream_t st = (hipStream_t)s;
     const double osz = a->max32 ? 4.0 / 32.0 : a->out_dtype == SPRC_F16X3 ? 6.0 : (double)dtype_size(a->out_dtype);
     const double np = b != nullptr ? 2.0 : 1.0;
@@ -79,7 +83,8 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     const double ka = a->k_alg > 0 ? (double)a->k_alg : (double)a->K;
     ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * ka,
                    np * (((double)a->M * ka + (double)a->N * ka) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))),
-                   np * 2.0 * a->M * (double)a->N * a->K);
+                   np * 2.0 * a->M * (double)a->N * ((double)a->K + a->k8));     // executed MACs: fp16 ones + e4m3 correction ones (half the time each)
+    if (a->k8 > 0) return gemm_dispatch_f16e(a, p, st);
     if (a->dtype == SPRC_FP8) return gemm_dispatch_fp8(a, p, st);
     if (a->dtype == SPRC_F16) return gemm_dispatch_f16(a, p, st);
     return a->dtype == SPRC_BF16 ? gemm_dispatch_bf16(a, p, st) : gemm_dispatch_f32(a, p, st);

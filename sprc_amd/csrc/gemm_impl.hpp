@@ -54,7 +54,13 @@ struct GemmParams {
     const float* w_scale; float a_scale;     // fp8 operands: acc * (a_scale * w_scale[n]) before the bias (null: no scaling)
     float out_scale;                    // fp8 output: value * out_scale before the conversion (1 / the consumer's dequantisation scale)
     int debug;                          // SPRC_GEMM_DEBUG on the 256x256 kernel: 64 s_memtime stamp build (tools/gemm_stamp.py)
+    int k8;                             // MIX kernels (split-precision products): e4m3 reduction elements that FOLLOW the K fp16 elements in
+                                        // every row of A and W (K-tiles of 128 bytes either way); their partial sum enters scaled by 2^-18
 };
+
+// MX block scales of the split-precision products' e4m3 segments: E8M0 118 = 2^-9 on BOTH operands -> 2^-18 on the product, the
+// factor the producers put in ([x_lo 2^12 | x] . [W 2^6 | W_lo 2^18], sprc.h: SPRC_F16X3).  One constant for every e4m3 K-tile.
+constexpr int MX_UNIT_SCALE = 0x7f7f7f7f, MX_SPLIT_SCALE = 0x76767676;
 
 __device__ __forceinline__ int64_t map_row_s(int shift, int stride, int off, int r) {
     if (shift < 0) return r;
@@ -86,16 +92,13 @@ __device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, b
 }
 // 4 consecutive outputs of one row: 16 B (fp32) or 8 B (bf16 / fp16)
 // n_split: logical row width N (SPRC_F16X3 outputs only: the lo / second-hi copies sit N and 2N elements further)
+// n_split / col: logical row width N and this quad's first column (SPRC_F16X3 outputs only: the e4m3 segments sit behind the N fp16 values)
 template <typename OutT>
-__device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v, int n_split = 0) {
+__device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v, int n_split = 0, int col = 0) {
     if constexpr (std::is_same<OutT, float>::value) {
         *reinterpret_cast<f32x4*>(dst) = v;
     } else if constexpr (std::is_same<OutT, f16x3_t>::value) {
-        f16x4 hi, lo;
-        split_f16x4(v[0], v[1], v[2], v[3], hi, lo);
-        *reinterpret_cast<f16x4*>(dst) = hi;
-        *reinterpret_cast<f16x4*>(dst + n_split) = lo;
-        *reinterpret_cast<f16x4*>(dst + 2 * n_split) = hi;
+        store_split4(reinterpret_cast<char*>(dst) - 2 * col, n_split, col, v[0], v[1], v[2], v[3]);
     } else if constexpr (std::is_same<OutT, f16_t>::value) {
         typedef __attribute__((ext_vector_type(4))) _Float16 half4;
         *reinterpret_cast<half4*>(dst) = half4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
@@ -109,14 +112,10 @@ __device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v, int n_spli
 
 // one output element (the ragged-N scalar path)
 template <typename OutT>
-__device__ __forceinline__ void store_out1(OutT* dst, float v, int n_split = 0) {
+__device__ __forceinline__ void store_out1(OutT* dst, float v, int n_split = 0, int col = 0) {
     if constexpr (std::is_same<OutT, fp8_t>::value) dst->bits = (uint8_t)(pack_fp8x2(v, 0.f, 0u, false) & 0xffu);
-    else if constexpr (std::is_same<OutT, f16x3_t>::value) {
-        _Float16 hi, lo;
-        split_f16(v, hi, lo);
-        _Float16* d = reinterpret_cast<_Float16*>(dst);
-        d[0] = hi; d[n_split] = lo; d[2 * n_split] = hi;
-    } else *dst = (OutT)v;
+    else if constexpr (std::is_same<OutT, f16x3_t>::value) store_split1(reinterpret_cast<char*>(dst) - 2 * col, n_split, col, v);
+    else *dst = (OutT)v;
 }
 
 template <typename T> struct Frag;
@@ -197,9 +196,9 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // volatile asm: as a pure intrinsic hipcc SINKS the MFMAs of a whole K-tile pair to the loop latch (legal, and fatal for the
 // interval structure); the statement stays where it is written.  Callers keep >= 8 other MFMAs between two uses of one
 // accumulator (no hazard nops are inserted for inline asm).
-__device__ __forceinline__ f32x16 mfma_mx8(const i32x8& bb, const i32x8& aa, f32x16 c) {
-    const int one = 0x7f7f7f7f;                             // E8M0 127 = 2^0 in every byte: unit block scales
-    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bb), "v"(aa), "v"(one));
+__device__ __forceinline__ f32x16 mfma_mx8(const i32x8& bb, const i32x8& aa, f32x16 c, int sc = MX_UNIT_SCALE) {
+    // sc: the E8M0 block scale of BOTH operands in every byte (0x7f = 2^0: unit scales; MX_SPLIT_SCALE for the split-precision segments)
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bb), "v"(aa), "v"(sc));
     return c;
 }
 // A 32-B MX operand = the 16-B fragments of two k-steps, read by compiler-tracked LDS loads so that the register allocator
@@ -210,15 +209,16 @@ __device__ __forceinline__ i32x8 lds_pair(uint32_t addr_lo, uint32_t addr_hi) {
     const u32x4 lo = *(lp)(addr_lo), hi = *(lp)(addr_hi);
     return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 }
+template <int SC = MX_UNIT_SCALE>
 __device__ __forceinline__ f32x16 mfma_mx(const u32x4& b0, const u32x4& b1, const u32x4& a0, const u32x4& a1, f32x16 c) {
     const i32x8 bb = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
     const i32x8 aa = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bb, aa, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bb, aa, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, SC, 0, SC);
 }
 
 // One K-tile of the 128x128 kernel on MX fp8: two K = 64 steps, each from a PAIR of 16-B fragments per operand row-tile; the
 // second pair is read and the next K-tile's loads are issued before the MFMAs of the first.
-template <int TM, int TN, int KT_BYTES, typename Issue>
+template <int TM, int TN, int KT_BYTES, int SC = MX_UNIT_SCALE, typename Issue>
 __device__ __forceinline__ void pipe_ktile_mx(uint32_t a_base, uint32_t b_base, uint32_t c0, f32x16 (&acc)[TM][TN], Issue&& issue) {
     static_assert(KT_BYTES == 128, "two K = 64 steps per K-tile");
     u32x4 fa[2][2][TM], fb[2][2][TN];           // [pair][fragment in pair][row-tile]
@@ -244,7 +244,7 @@ __device__ __forceinline__ void pipe_ktile_mx(uint32_t a_base, uint32_t b_base, 
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
             for (int ni = 0; ni < TN; ++ni)
-                acc[mi][ni] = mfma_mx(fb[pr][0][ni], fb[pr][1][ni], fa[pr][0][mi], fa[pr][1][mi], acc[mi][ni]);
+                acc[mi][ni] = mfma_mx<SC>(fb[pr][0][ni], fb[pr][1][ni], fa[pr][0][mi], fa[pr][1][mi], acc[mi][ni]);
         __builtin_amdgcn_s_setprio(0);
     });
 }
@@ -395,7 +395,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         const int row = block_row(mi, it);
                         if (!(row < p.M && col_ok)) continue;
                         const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, row);
-                        store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v, p.N);
+                        store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v, p.N, col);
                     }
                     if constexpr (RES) {
                         if (mi + 2 < TM) load_resid(mi + 2, rv[mi & 1]);
@@ -444,7 +444,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         if constexpr (ACT == SPRC_ACT_QUICKGELU) v = quick_gelu(v);
                         if (rrow != nullptr) v += rrow[col];
                         if constexpr (std::is_same<OutT, fp8_t>::value) v *= p.out_scale;
-                        store_out1<OutT>(crow + col, v, p.N);
+                        store_out1<OutT>(crow + col, v, p.N, col);
                     }
             }
         }
@@ -455,10 +455,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // workgroups share a CU and cover each other's waits.  4: a ring three K-tiles deep with counted waits, for the launches that
 // cannot even give every CU a workgroup (remainder rows, the small Q-Former products): there a K-tile cost a full memory
 // round trip (~1.5 k cycles for 4 MFMAs; the 128-row ViT remainders 20 us per launch).
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int NS = 2>
+// MIX (fp16 operands only): the split-precision product -- the K fp16 elements of every operand row are followed by p.k8 e4m3 elements
+// (sprc.h: SPRC_F16X3); their K-tiles run on the MX-scaled MFMA into the same accumulators.
+template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int NS = 2, bool MIX = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(NS == 2 || (NS == 4 && sizeof(T) <= 2), "stages: 2, or a ring of 4 for 1- and 2-byte operands");
+    static_assert(!MIX || std::is_same<T, f16_t>::value, "MIX: fp16 main segment");
     constexpr int KT_BYTES = 128;
     constexpr int NT = 64 * WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int STAGE_BYTES = (BM + BN) * KT_BYTES;
@@ -471,6 +474,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     const int r32 = lane & 31, half = lane >> 5;
     const int nwg = p.tiles_m * p.tiles_n;
     int nt = (int)(((int64_t)p.K * sizeof(T)) / KT_BYTES);
+    int nt16 = nt;                                              // MIX: K-tiles [0, nt16) are fp16, [nt16, nt) e4m3
+    if constexpr (MIX) nt += p.k8 / KT_BYTES;
     int vb = blockIdx.x, ks = 0;
     if (p.dual && vb >= p.nwg0) {                               // second product of a paired launch
         vb -= p.nwg0;
@@ -482,6 +487,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
         vb -= ks * nwg;
         const int per = (nt + p.ksplit - 1) / p.ksplit, t0 = min(ks * per, nt);
         nt = min(per, nt - t0);
+        nt16 = max(0, min(nt16 - t0, nt));
         kbase = (int64_t)t0 * KT_BYTES;
     }
 
@@ -561,7 +567,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
                     if (more) static_for<kk * LQ, (kk + 1) * LQ>([&](auto j_) { stage_one(j_, dst, ko); });
                 };
                 if constexpr (sizeof(T) == 1 && SPRC_FP8_MX) pipe_ktile_mx<TM, TN, KT_BYTES>(so + a_off, so + b_off, c0, acc, issue);
-                else pipe_ktile_bf16<TM, TN, KT_BYTES, T>(so + a_off, so + b_off, c0, acc, issue);
+                else if constexpr (MIX) {
+                    if (t < nt16) pipe_ktile_bf16<TM, TN, KT_BYTES, T>(so + a_off, so + b_off, c0, acc, issue);
+                    else pipe_ktile_mx<TM, TN, KT_BYTES, MX_SPLIT_SCALE>(so + a_off, so + b_off, c0, acc, issue);
+                } else pipe_ktile_bf16<TM, TN, KT_BYTES, T>(so + a_off, so + b_off, c0, acc, issue);
             } else {
                 if (more) {
                     char* dst = smem + ((t + 1) & 1) * STAGE_BYTES + wave * 1024;
@@ -627,7 +636,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
         if (resid != nullptr) v[e] += resid[(int64_t)row * ldr + col + e];
         if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= out_scale;
-        store_out1<OutT>(C + (int64_t)row * ldc + col + e, v[e], N);
+        store_out1<OutT>(C + (int64_t)row * ldc + col + e, v[e], N, col + e);
     }
 }
 
@@ -654,10 +663,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //        G0 after C(t,1) (4t+3: B0 B1 of t+1) and after NC(t,0) (4t: A2 A3 of t); G1 after NC(t,1) (4t+3: A0 A1 B2 B3 of
 //        t+1).  Every piece has >= 2 intervals between issue and wait.
 //   WAR  a piece is restaged >= 1 interval after the barrier that followed the last read of the region it overwrites.
-template <typename T, typename OutT, int ACT, bool MAX32, bool STAMP = false>
+// MIX (T = fp16): split-precision product.  Operand rows = K fp16 elements + p.k8 e4m3 elements; the K loop runs the fp16 K-tiles on
+// v_mfma_f32_32x32x16_f16 and then the e4m3 K-tiles on the MX-scaled MFMA (block scales 2^-9 x 2^-9) into the SAME accumulators: the
+// staging, the LDS image and the interval schedule do not know the element type (a K-tile is 128 bytes of a row either way); only the
+// fragment registers and the cluster's instruction differ -- two copies of the steady interval pair, selected at compile time.
+template <typename T, typename OutT, int ACT, bool MAX32, bool STAMP = false, bool MIX = false>
 __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(sizeof(T) <= 2, "16-bit or fp8 operands");
+    static_assert(!MIX || (std::is_same<T, f16_t>::value && SPRC_FP8_MX), "MIX: fp16 main segment + MX e4m3 segments");
     constexpr bool FP8 = sizeof(T) == 1;
     constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
     constexpr int BM = 256, BN = 256;
@@ -665,7 +679,8 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     const int wr = __builtin_amdgcn_readfirstlane(wave / WN), wc = wave % WN;   // wr doubles as the phase group (SGPR: barriers under it)
     const int r32 = lane & 31, half = lane >> 5;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int nt = FP8 ? p.K / 128 : p.K / 64;             // K-tiles of 128 bytes
+    const int nt16 = MIX ? p.K / 64 : 0;                    // MIX: fp16 K-tiles [0, nt16) (even), then e4m3 K-tiles
+    const int nt = FP8 ? p.K / 128 : p.K / 64 + (MIX ? p.k8 / 128 : 0);             // K-tiles of 128 bytes
     uint64_t tile_ts[4] = {0, 0, 0, 0};                      // STAMP build: entry | prologue done | K loop done | epilogue done
     uint64_t pro_ts[3] = {0, 0, 0};                         // STAMP build, inside the prologue: setup done | loads issued | loads landed
     if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
@@ -746,6 +761,9 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         addr_b[x] = lds0 + B_BASE + (wc * TN * 32 + r32) * KTB + (c0 ^ (uint32_t)(x << 5));
     }
     constexpr bool MX = FP8 && SPRC_FP8_MX;
+    typedef std::integral_constant<bool, MIX || MX> MXL;    // element kind of a K-tile: MXL for every tile of a plain kernel; MIX kernels
+                                                            // pass false_type for their fp16 tiles and MXL (= true) for the e4m3 ones
+    constexpr int MXSC = MIX ? MX_SPLIT_SCALE : MX_UNIT_SCALE;
     u32x4 fa[2][TM], fb[2][TN];
     i32x8 fa8[TM], fb8[TN];                                 // MX: both k-steps of a cluster in one 8-register operand
     // (A residual PREFETCH -- throw-away dword loads over the tile's residual lines in the last K-tile -- paid while the epilogue
@@ -770,9 +788,9 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     };
     auto piece = [&](auto q_, uint32_t par_bytes, int tile) { load_piece(q_, I0{}, par_bytes, tile); load_piece(q_, I1{}, par_bytes, tile); };
     // fragments of k-steps 2h, 2h+1 of the K-tile in the stage of parity PAR: compile-time parity = pure immediates
-    auto reads_c = [&](auto par_, auto h_) {
+    auto reads_c = [&](auto par_, auto h_, auto mx_) {
         constexpr int PAR = decltype(par_)::value, h = decltype(h_)::value;
-        if constexpr (MX) {
+        if constexpr (decltype(mx_)::value) {
             static_for<0, TM>([&](auto i) {
                 constexpr uint32_t off = PAR * PAR_BYTES + decltype(i)::value * 32 * KTB;
                 fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + off, addr_a[2 * h + 1] + off);
@@ -789,9 +807,9 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             static_for<0, TN>([&](auto i) { fb[k][i] = lds_read128<PAR * PAR_BYTES + decltype(i)::value * 32 * KTB>(addr_b[2 * h + k]); });
         });
     };
-    auto reads_r = [&](uint32_t par_bytes, auto h_) {       // run-time parity (the last K-tiles)
+    auto reads_r = [&](uint32_t par_bytes, auto h_, auto mx_) {       // run-time parity (the last K-tiles)
         constexpr int h = decltype(h_)::value;
-        if constexpr (MX) {
+        if constexpr (decltype(mx_)::value) {
             static_for<0, TM>([&](auto i) {
                 constexpr uint32_t off = decltype(i)::value * 32 * KTB;
                 fa8[decltype(i)::value] = lds_pair(addr_a[2 * h] + par_bytes + off, addr_a[2 * h + 1] + par_bytes + off);
@@ -811,12 +829,12 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     };
     // 16 MFMAs (k-steps 2h, 2h+1 of the 128 x 64 wave tile); the second load of piece q goes out after MFMA number
     // SPRC_ANTI_LDPOS (`ld`: a compile-time true in the steady state, a run-time flag in the last K-tiles)
-    auto cluster = [&](auto q_, uint32_t par_bytes, auto ld, int tile) {
+    auto cluster = [&](auto q_, uint32_t par_bytes, auto ld, int tile, auto mx_) {
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (FP8 && SPRC_FP8_MX) {
+        if constexpr (decltype(mx_)::value) {
             static_for<0, 8>([&](auto x_) {
                 constexpr int x = decltype(x_)::value, mi = x >> 1, ni = x & 1;
-                acc[mi][ni] = mfma_mx8(fb8[ni], fa8[mi], acc[mi][ni]);
+                acc[mi][ni] = mfma_mx8(fb8[ni], fa8[mi], acc[mi][ni], MXSC);
                 if constexpr (x == (SPRC_ANTI_LDPOS) / 2) { if (ld) load_piece(q_, I1{}, par_bytes, tile); }
             });
         } else {
@@ -836,13 +854,13 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     // NC(t,1) stages K-tile t+1 (G0) or t+2 (G1): tile index and stage parity of that piece pair
     const uint32_t p2_bytes[2] = {wr ? 0u : PAR_BYTES, wr ? PAR_BYTES : 0u};      // indexed by the parity of t
     // steady state: K-tiles t+1 and t+2 exist, parity of t known at compile time -> no branch but the group's waits
-    auto steady = [&](auto par_, int t) {
+    auto steady = [&](auto par_, int t, auto mx_) {
         constexpr int PAR = decltype(par_)::value;
         constexpr uint32_t pn = (PAR ^ 1) * PAR_BYTES;
         const uint32_t p2 = p2_bytes[PAR];
         const int t_p2 = t + 1 + wr;
         stamp(integral_constant<int, 0>{}, t);
-        reads_c(par_, I0{});                                // NC(t,0)
+        reads_c(par_, I0{}, mx_);                           // NC(t,0)
         piece(I0{}, pn, t + 1);
         load_piece(I1{}, I0{}, pn, t + 1);
         stamp(integral_constant<int, 1>{}, t);
@@ -851,11 +869,11 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         stamp(integral_constant<int, 2>{}, t);
         barrier();
         stamp(integral_constant<int, 3>{}, t);
-        cluster(I1{}, pn, std::true_type{}, t + 1);         // C(t,0)
+        cluster(I1{}, pn, std::true_type{}, t + 1, mx_);    // C(t,0)
         stamp(integral_constant<int, 4>{}, t);
         barrier();
         stamp(integral_constant<int, 5>{}, t);
-        reads_c(par_, I1{});                                // NC(t,1)
+        reads_c(par_, I1{}, mx_);                           // NC(t,1)
         piece(I2{}, p2, t_p2);
         load_piece(I3{}, I0{}, p2, t_p2);
         stamp(integral_constant<int, 6>{}, t);
@@ -864,7 +882,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         stamp(integral_constant<int, 7>{}, t);
         barrier();
         stamp(integral_constant<int, 8>{}, t);
-        cluster(I3{}, p2, std::true_type{}, t_p2);          // C(t,1)
+        cluster(I3{}, p2, std::true_type{}, t_p2, mx_);     // C(t,1)
         stamp(integral_constant<int, 9>{}, t);
         if (wr == 0) wait_vmcnt<4>();                       // B0 B1 of t+1 landed; A2 A3 of t+1 may fly
         stamp(integral_constant<int, 10>{}, t);
@@ -872,24 +890,24 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         stamp(integral_constant<int, 11>{}, t);
     };
     // the last (up to three) K-tiles: the same interval structure on run-time flags
-    auto tail = [&](int t, bool n1, bool n2) {
+    auto tail = [&](int t, bool n1, bool n2, auto mx_) {
         const uint32_t pb = (uint32_t)(t & 1) * PAR_BYTES, pn = pb ^ PAR_BYTES;
         const uint32_t p2 = wr ? pb : pn;
         const int t_p2 = t + 1 + wr;
         const bool has_p2 = wr ? n2 : n1;
-        reads_r(pb, I0{});                                  // NC(t,0)
+        reads_r(pb, I0{}, mx_);                             // NC(t,0)
         if (n1) { piece(I0{}, pn, t + 1); load_piece(I1{}, I0{}, pn, t + 1); }
         wait_lgkmcnt<0>();
         if (wr == 0) { if (n1) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
         barrier();
-        cluster(I1{}, pn, n1, t + 1);                       // C(t,0)
+        cluster(I1{}, pn, n1, t + 1, mx_);                  // C(t,0)
         barrier();
-        reads_r(pb, I1{});                                  // NC(t,1)
+        reads_r(pb, I1{}, mx_);                             // NC(t,1)
         if (has_p2) { piece(I2{}, p2, t_p2); load_piece(I3{}, I0{}, p2, t_p2); }
         wait_lgkmcnt<0>();
         if (wr == 1) { if (n2) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
         barrier();
-        cluster(I3{}, p2, has_p2, t_p2);                    // C(t,1)
+        cluster(I3{}, p2, has_p2, t_p2, mx_);               // C(t,1)
         if (wr == 0) { if (n1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
         barrier();
     };
@@ -910,11 +928,17 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
     {
         int t = 0;
-        for (; t + 3 < nt; t += 2) {
-            steady(I0{}, t);
-            steady(I1{}, t + 1);
+        if constexpr (MIX) {                                // fp16 K-tiles (nt16 even; >= 4 e4m3 K-tiles follow, so t + 3 < nt holds throughout)
+            for (; t + 1 < nt16; t += 2) {
+                steady(I0{}, t, std::false_type{});
+                steady(I1{}, t + 1, std::false_type{});
+            }
         }
-        for (; t < nt; ++t) tail(t, t + 1 < nt, t + 2 < nt);
+        for (; t + 3 < nt; t += 2) {
+            steady(I0{}, t, MXL{});
+            steady(I1{}, t + 1, MXL{});
+        }
+        for (; t < nt; ++t) tail(t, t + 1 < nt, t + 2 < nt, MXL{});
     }
     if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
     if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
@@ -996,13 +1020,13 @@ static SideStream* side_stream() {
     return state[dev] == 1 ? &pool[dev] : nullptr;
 }
 
-template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT, int NS = 2>
+template <typename T, typename OutT, int ACT, bool MAX32, int WM, int WN, int TM, int TN, int RESIDENT, int NS = 2, bool MIX = false>
 static int launch_cfg(GemmParams p, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32, LDS = NS * (BM + BN) * 128;
     // (A persistent variant -- grid = CUs x residency with the next tile's first K-tile prefetched before the epilogue --
     // measured equal to one workgroup per tile on MI355X while costing ~45 VGPRs: all tiles take the same time, so the
     // CUs stay in lockstep and the output-write bursts still coincide.  Removed.)
-    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN, NS>;
+    auto kern = gemm_kernel<T, OutT, ACT, MAX32, WM, WN, TM, TN, NS, MIX>;
     static bool attr_set[MAX_DEVICES] = {false};
     optin_lds(kern, LDS, attr_set);
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -1016,10 +1040,10 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     return SPRC_OK;
 }
 
-template <typename T, typename OutT, int ACT, bool MAX32>
+template <typename T, typename OutT, int ACT, bool MAX32, bool MIX = false>
 static int launch_anti(GemmParams p, hipStream_t st) {
     constexpr int LDS = 2 * 512 * 128;
-    auto kern = gemm_anti_kernel<T, OutT, ACT, MAX32, false>;
+    auto kern = gemm_anti_kernel<T, OutT, ACT, MAX32, false, MIX>;
     if constexpr (std::is_same<T, bf16_t>::value && std::is_same<OutT, bf16_t>::value && ACT == SPRC_ACT_NONE && !MAX32) {
         if ((p.debug & 64) && p.resid != nullptr) {         // phase-timestamp build (tools/gemm_stamp.py)
             auto sk = gemm_anti_kernel<T, OutT, ACT, MAX32, true>;
@@ -1054,9 +1078,10 @@ static bool fits_u32(const GemmParams& p) {
            p.lda_b < (1 << 24) && p.ldw_b < (1 << 24);          // the 256 x 256 kernel forms row offsets with 24-bit multiplies
 }
 
-template <typename T, typename OutT, int ACT, bool MAX32>
+template <typename T, typename OutT, int ACT, bool MAX32, bool MIX = false>
 static int launch(const GemmParams& p, hipStream_t st) {
     static const int forced = env_int("SPRC_GEMM_TILE", 0);
+    const int keff = MIX ? p.K + p.k8 / 2 : p.K;                // reduction length in units of 16-bit elements (time ~ bytes of a row)
     int cfg = forced;
     if constexpr (sizeof(T) <= 2) {
         if (cfg == 0) {
@@ -1073,7 +1098,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
             // a short reduction with an fp32 + residual epilogue spends as long writing out (an HBM burst no other workgroup
             // on the CU can hide) as in its K loop: +35 % per round (14912 x 768 x 768: 46 us on 256x256, 40 on 128x128;
             // 32896 x 1024 x 1024: 131 us peeled, 118 on 128x128)
-            const double f256 = (p.K <= 1024 && sizeof(OutT) == 4 && p.resid != nullptr) ? 1.35 : 1.0;
+            const double f256 = (keff <= 1024 && sizeof(OutT) == 4 && p.resid != nullptr) ? 1.35 : 1.0;
             const int64_t mult = p.dual ? 2 : 1;                 // a paired launch carries two products
             auto cost256 = [&](int m) { return f256 * (double)((mult * ((int64_t)(m + 255) / 256) * tn256 + ncu - 1) / ncu); };
             auto cost128 = [&](int m) {
@@ -1115,21 +1140,21 @@ static int launch(const GemmParams& p, hipStream_t st) {
                     (void)hipStreamWaitEvent(ss->st, ss->fork, 0);
                     sr = ss->st;
                 }
-                const int rc = launch_anti<T, OutT, ACT, MAX32>(pm, st);
+                const int rc = launch_anti<T, OutT, ACT, MAX32, MIX>(pm, st);
                 if (rc != SPRC_OK) return rc;
                 const int rr = [&]() -> int {
                 hipStream_t st = sr;                 // (shadows the caller's stream inside the remainder launches)
                 // remainder rows: a long reduction on a handful of workgroups is latency-bound (11 WGs x 96 K-tiles = 77 us
                 // for the ViT fc2) -> split K over 8 workgroups per tile into caller scratch and reduce in a fixed order
                 constexpr int S = 8;
-                if (rem <= 128 && p.K >= 4096 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.scratch != nullptr &&
+                if (rem <= 128 && keff >= 4096 && p.N % 4 == 0 && p.ldc % 4 == 0 && p.scratch != nullptr &&
                     p.scratch_elems >= (int64_t)S * rem * p.N) {
                     GemmParams ps = pt;
                     ps.C = p.scratch; ps.ldc = p.N; ps.bias = nullptr; ps.resid = nullptr; ps.ldr = 0; ps.w_scale = nullptr;
                     ps.ksplit = S; ps.split_stride = (int64_t)rem * p.N;
                     static const int ring = env_int("SPRC_GEMM_RING", 1);   // a handful of workgroups: ring of 4 stages (0: two stages, A/B)
-                    const int rs = ring ? launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 1, 4>(ps, st)
-                                        : launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 2>(ps, st);
+                    const int rs = ring ? launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 1, 4, MIX>(ps, st)
+                                        : launch_cfg<T, float, SPRC_ACT_NONE, false, 2, 2, 2, 2, 2, 2, MIX>(ps, st);
                     if (rs != SPRC_OK) return rs;
                     const int64_t n = (int64_t)rem * (p.N / 4);
                     hipLaunchKernelGGL((splitk_reduce_kernel<OutT, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
@@ -1141,9 +1166,9 @@ static int launch(const GemmParams& p, hipStream_t st) {
                 if constexpr (sizeof(T) == 2 && !MAX32) {
                     static const int ring = env_int("SPRC_GEMM_RING", 1);
                     if (((rem + 127) / 128) * tn128 <= ncu)
-                        return ring ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4>(pt, st) : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(pt, st);
+                        return ring ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4, MIX>(pt, st) : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4, 2, MIX>(pt, st);
                 }
-                return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(pt, st);
+                return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2, 2, MIX>(pt, st);
                 }();
                 if (ss != nullptr) {
                     (void)hipEventRecord(ss->join, sr);
@@ -1159,21 +1184,21 @@ static int launch(const GemmParams& p, hipStream_t st) {
             if (cfg == 2 && !MAX32 && sizeof(T) == 2 && mult * ((p.M + 127) / 128) * tn128 <= ncu) cfg = 1;
         }
         // 256x256 tile: anti-phase schedule by default (SPRC_GEMM_TILE=14 forces the lock-step kernel for A/B runs)
-        if (cfg == 4 || cfg == 10) return launch_anti<T, OutT, ACT, MAX32>(p, st);
+        if (cfg == 4 || cfg == 10) return launch_anti<T, OutT, ACT, MAX32, MIX>(p, st);
     } else {
         if (cfg == 0) cfg = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) >= 1024 ? 4 : 2;
     }
-    if (cfg == 4 || cfg == 10 || cfg == 14) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st);
+    if constexpr (!MIX) { if (cfg == 4 || cfg == 10 || cfg == 14) return launch_cfg<T, OutT, ACT, MAX32, 2, 4, 4, 2, 1>(p, st); }
     if constexpr (sizeof(T) == 2 && !MAX32) {
         if (cfg == 1) {                                     // 64 x 64 tile: small latency-bound products; ring of 4 stages (64 KB) or 2 (32 KB)
             // (the ring's 64 KB leave two workgroups per CU: only for grids that fit then -- 768 workgroups ran 5 % slower on it)
             static const int ring = env_int("SPRC_GEMM_RING", 1);
             const int64_t nwg64 = (p.dual ? 2 : 1) * (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-            return ring && nwg64 <= 2 * num_cus() ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4>(p, st)
-                                                  : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4>(p, st);
+            return ring && nwg64 <= 2 * num_cus() ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4, MIX>(p, st)
+                                                  : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4, 2, MIX>(p, st);
         }
     }
-    return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2>(p, st);
+    return launch_cfg<T, OutT, ACT, MAX32, 2, 2, 2, 2, 2, 2, MIX>(p, st);
 }
 
 template <typename T>
@@ -1226,7 +1251,23 @@ static int dispatch(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st
 }
 
 
+// split-precision products (fp16 + e4m3 segments): the epilogues the fp16 engine's Q-Former and patch embedding use
+template <typename T>                       // (a template so that only gemm_f16e.hip instantiates the kernels)
+static int dispatch_mix(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st) {
+    static_assert(std::is_same<T, f16_t>::value, "split-precision products have an fp16 main segment");
+    if (a->act != SPRC_ACT_NONE && a->act != SPRC_ACT_GELU) { set_error("sprc_gemm(k8): activation %d is not built for split-precision products", a->act); return SPRC_EUNSUPPORTED; }
+    const bool gelu = a->act == SPRC_ACT_GELU;
+    switch (a->out_dtype) {
+        case SPRC_F16X3: return gelu ? launch<f16_t, f16x3_t, SPRC_ACT_GELU, false, true>(p, st) : launch<f16_t, f16x3_t, SPRC_ACT_NONE, false, true>(p, st);
+        case SPRC_F16: return gelu ? launch<f16_t, f16_t, SPRC_ACT_GELU, false, true>(p, st) : launch<f16_t, f16_t, SPRC_ACT_NONE, false, true>(p, st);
+        case SPRC_F32: return gelu ? launch<f16_t, float, SPRC_ACT_GELU, false, true>(p, st) : launch<f16_t, float, SPRC_ACT_NONE, false, true>(p, st);
+    }
+    set_error("sprc_gemm(k8): out_dtype %d does not go with a split-precision product", a->out_dtype);
+    return SPRC_EUNSUPPORTED;
+}
+
 // per-operand-type dispatchers, one translation unit each
+int gemm_dispatch_f16e(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);
 int gemm_dispatch_bf16(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);
 int gemm_dispatch_f16(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);
 int gemm_dispatch_f32(const sprc_gemm_args* a, const GemmParams& p, hipStream_t st);

@@ -28,10 +28,28 @@ struct Fp8Scales { const float* w_scale; float a_scale, out_scale; };
 static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
                 void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0,
                 sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0,
-                const Fp8Scales* q = nullptr, int64_t ldw = 0, int k_alg = 0) {
+                const Fp8Scales* q = nullptr, int64_t ldw = 0, int k8 = 0) {
     sprc_gemm_args g;
     memset(&g, 0, sizeof(g));
-    g.k_alg = k_alg;
+    g.k8 = k8;
+    if (q != nullptr) { g.w_scale = q->w_scale; g.a_scale = q->a_scale; g.out_scale = q->out_scale; }
+    g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
+    g.A = A; g.lda = lda; g.amap = amap;
+    g.W = w.w; g.ldw = ldw > 0 ? ldw : K; g.bias = w.b;
+    g.resid = resid; g.ldr = ldr;
+    g.C = C; g.ldc = ldc; g.cmap = cmap;
+    g.scratch = scratch; g.scratch_bytes = scratch_bytes;
+    return sprc_gemm(&g, st);
+}
+
+// the same with an algorithmic reduction length for the profiler (the patch embedding launches its zero-padded K)
+static int gemm_ka(int k_alg, hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
+                   void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0, sprc_rowmap amap = ID_MAP,
+                   sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0, const Fp8Scales* q = nullptr, int64_t ldw = 0,
+                   int k8 = 0) {
+    sprc_gemm_args g;
+    memset(&g, 0, sizeof(g));
+    g.k8 = k8; g.k_alg = k_alg;
     if (q != nullptr) { g.w_scale = q->w_scale; g.a_scale = q->a_scale; g.out_scale = q->out_scale; }
     g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
     g.A = A; g.lda = lda; g.amap = amap;
@@ -45,11 +63,11 @@ static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const v
 // two products of identical shape in one launch (sprc_gemm_pair): w0 on the rows amap0 -> cmap0, w1 on amap1 -> cmap1
 static int gemm2(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w0,
                  const sprc_linear& w1, void* C, int64_t ldc, int act, const float* resid, int64_t ldr, sprc_rowmap amap0,
-                 sprc_rowmap amap1, sprc_rowmap cmap0, sprc_rowmap cmap1, int64_t ldw = 0, int k_alg = 0) {
+                 sprc_rowmap amap1, sprc_rowmap cmap0, sprc_rowmap cmap1, int64_t ldw = 0, int k8 = 0) {
     sprc_gemm_args g[2];
     memset(g, 0, sizeof(g));
     for (int i = 0; i < 2; ++i) {
-        g[i].k_alg = k_alg;
+        g[i].k8 = k8;
         g[i].M = M; g[i].N = N; g[i].K = K; g[i].dtype = dt; g[i].out_dtype = out_dt; g[i].act = act;
         g[i].A = A; g[i].lda = lda; g[i].amap = i ? amap1 : amap0;
         g[i].W = (i ? w1 : w0).w; g[i].ldw = ldw > 0 ? ldw : K; g[i].bias = (i ? w1 : w0).b;
@@ -63,7 +81,7 @@ static int gemm2(hipStream_t st, int dt, int out_dt, int M, int N, int K, const 
 static int lnorm(hipStream_t st, int dt, int M, int D, const float* x, const float* gam, const float* bet, float eps,
                  float* y32, void* y16, sprc_rowmap map = ID_MAP, const void* add16 = nullptr, float* sum32 = nullptr,
                  float y16_scale = 0.f) {
-    const int64_t ld16 = dt == SPRC_F16X3 ? 3 * (int64_t)D : D;
+    const int64_t ld16 = dt == SPRC_F16X3 ? 2 * (int64_t)D : D;          // fp16 units: a split row is 4 D bytes
     sprc_layernorm_args a;
     memset(&a, 0, sizeof(a));
     a.M = M; a.D = D; a.out_dtype = dt;
@@ -128,7 +146,7 @@ struct VitBufs { void *rows, *h, *qkv, *ctx, *mlp; float *pout, *x; };
 static size_t vit_plan(const sprc_vit_model* m, int B, Bump& b, VitBufs& v) {
     const size_t es = dtype_size(m->dtype);
     const size_t M = (size_t)B * m->tokens, P = (size_t)B * (m->tokens - 1), D = m->width;
-    v.rows = b.take(P * m->patch_k_pad * es * (m->patch_x3 ? 3 : 1));
+    v.rows = b.take(P * m->patch_k_pad * es * (m->patch_x3 ? 2 : 1));          // split rows: 4 bytes per column
     v.pout = (float*)b.take(P * D * 4);
     v.x = (float*)b.take(M * D * 4);
     v.h = b.take(M * D * es);
@@ -148,8 +166,8 @@ static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& 
     const size_t es = dtype_size(m->dtype);
     const size_t S = (size_t)m->num_query + m->max_txt, R = (size_t)B * S, Hd = m->hidden;
     const size_t E = (size_t)B * enc_tokens;
-    const size_t kx = m->x3 ? 3 : 1;               // split-precision Q-Former: GEMM input activations are [hi | lo | hi]
-    q.enc = (with_kv && is16(m->dtype)) ? b.take(E * m->enc_width * es * ((m->x3 & SPRC_X3_CKV) ? 3 : 1)) : nullptr;
+    const size_t kx = m->x3 ? 2 : 1;               // split-precision Q-Former: GEMM input activations are split rows (SPRC_F16X3: 4 B / column)
+    q.enc = (with_kv && is16(m->dtype)) ? b.take(E * m->enc_width * es * ((m->x3 & SPRC_X3_CKV) ? 2 : 1)) : nullptr;
     q.kv = with_kv ? b.take(E * (size_t)m->n_cross * 2 * Hd * es) : nullptr;
     q.h32 = (float*)b.take(R * Hd * 4); q.h16 = b.take(R * Hd * es * kx);
     q.a32 = (float*)b.take(R * Hd * 4); q.a16 = b.take(R * Hd * es * kx);
@@ -186,9 +204,9 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
     const int dt = m->dtype, Hd = m->hidden, H = m->heads, dh = m->head_dim, F = m->ffn, Lq = m->num_query;
     const X3Layouts lay = x3_layouts(cm);
     const int adt = lay.ln ? SPRC_F16X3 : dt, fdt = lay.ffn ? SPRC_F16X3 : dt;      // dtype of the LayerNorm copies / the FFN hidden
-    const int KH = lay.ln ? 3 * Hd : Hd, KC = lay.ctx ? 3 * Hd : Hd, KF = lay.ffn ? 3 * F : F;   // their leading dimensions (ctx: KC)
-    auto kdim = [&](int kind, int width) { return (cm & kind) ? 3 * width : width; };          // reduction length of a layer
-    auto wld = [&](int kind, int width) { return (int64_t)((m->x3 & kind) ? 3 * width : width); };   // its weights' leading dimension
+    const int KH = lay.ln ? 2 * Hd : Hd, KC = lay.ctx ? 2 * Hd : Hd, KF = lay.ffn ? 2 * F : F;   // their leading dimensions in fp16 units (ctx: KC)
+    auto k8of = [&](int kind, int width) { return (cm & kind) ? 2 * width : 0; };              // e4m3 correction elements a layer of this call reduces over
+    auto wld = [&](int kind, int width) { return (int64_t)((m->x3 & kind) ? 2 * width : width); };   // its weights' leading dimension (fp16 units)
     const int R = B * S;
     const float sc = 1.0f / sqrtf((float)dh);                                   // Qformer.py:250
     const size_t es = dtype_size(dt);
@@ -200,8 +218,8 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
     // y = act(in . W^T + b) of layer kind `kind` over `width` input columns, into a compute-dtype (or x3) buffer
     auto lin = [&](int kind, int rows, int N, int width, const void* in, int64_t lda, const sprc_linear& w, int odt, void* out,
                    int64_t ldc, int act, sprc_rowmap amap, sprc_rowmap cmap) -> int {
-        return gemm(st, dt, odt, rows, N, kdim(kind, width), in, lda, w, out, ldc, act, nullptr, 0, amap, cmap, nullptr, 0, nullptr,
-                    wld(kind, width), width);
+        return gemm(st, dt, odt, rows, N, width, in, lda, w, out, ldc, act, nullptr, 0, amap, cmap, nullptr, 0, nullptr,
+                    wld(kind, width), k8of(kind, width));
     };
     // a = LN(dense(in) + res): branch GEMM of layer kind `kind` over `width` input columns, post-LN into (o32, o16)
     auto branch = [&](int kind, int rows, int width, int64_t lda, const void* in, const sprc_linear& w, const float* res,
@@ -210,8 +228,8 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
             RUN(gemm(st, dt, SPRC_F16, rows, Hd, width, in, lda, w, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, amap, cmap));
             return lnorm(st, dt, rows, Hd, res, lw, lb, m->ln_eps, o32, o16, cmap, q.a16);
         }
-        RUN(gemm(st, dt, SPRC_F32, rows, Hd, kdim(kind, width), in, lda, w, q.t32, Hd, SPRC_ACT_NONE, res, Hd, amap, cmap, nullptr, 0,
-                 nullptr, wld(kind, width), width));
+        RUN(gemm(st, dt, SPRC_F32, rows, Hd, width, in, lda, w, q.t32, Hd, SPRC_ACT_NONE, res, Hd, amap, cmap, nullptr, 0,
+                 nullptr, wld(kind, width), k8of(kind, width)));
         return lnorm(st, adt, rows, Hd, q.t32, lw, lb, m->ln_eps, o32, o16, cmap);
     };
     for (int l = 0; l < m->n_layers; ++l) {
@@ -238,16 +256,16 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
                 // products have the same shape, so each pair is ONE launch (sprc_gemm_pair) -- 360 + 360 tiles instead of two
                 // 1.4-round grids for the up projection, 90 + 90 instead of two third-empty grids for the down projection.
                 // The hidden activations keep the rows' natural positions in q.ffn [R, F].
-                RUN(gemm2(st, dt, fdt, Rq, F, kdim(SPRC_X3_FFN_IN, Hd), q.a16, KH, L.ffn_q_in, L.ffn_t_in, q.ffn, KF, SPRC_ACT_GELU, nullptr, 0,
-                          qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_IN, Hd), Hd));
+                RUN(gemm2(st, dt, fdt, Rq, F, Hd, q.a16, KH, L.ffn_q_in, L.ffn_t_in, q.ffn, KF, SPRC_ACT_GELU, nullptr, 0,
+                          qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_IN, Hd), k8of(SPRC_X3_FFN_IN, Hd)));
                 if (fuse_add) {
                     RUN(gemm2(st, dt, SPRC_F16, Rq, Hd, F, q.ffn, F, L.ffn_q_out, L.ffn_t_out, q.a16, Hd, SPRC_ACT_NONE, nullptr, 0, qmap,
                               tmap, qmap, tmap));
                     RUN(lnorm(st, dt, Rq, Hd, q.a32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, qmap, q.a16));
                     RUN(lnorm(st, dt, Rq, Hd, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap, q.a16));
                 } else {
-                    RUN(gemm2(st, dt, SPRC_F32, Rq, Hd, kdim(SPRC_X3_FFN_OUT, F), q.ffn, KF, L.ffn_q_out, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE,
-                              q.a32, Hd, qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_OUT, F), F));
+                    RUN(gemm2(st, dt, SPRC_F32, Rq, Hd, F, q.ffn, KF, L.ffn_q_out, L.ffn_t_out, q.t32, Hd, SPRC_ACT_NONE,
+                              q.a32, Hd, qmap, tmap, qmap, tmap, wld(SPRC_X3_FFN_OUT, F), k8of(SPRC_X3_FFN_OUT, F)));
                     RUN(lnorm(st, adt, Rq, Hd, q.t32, L.ffn_q_ln_w, L.ffn_q_ln_b, m->ln_eps, x32, x16, qmap));
                     RUN(lnorm(st, adt, Rq, Hd, q.t32, L.ffn_t_ln_w, L.ffn_t_ln_b, m->ln_eps, x32, x16, tmap));
                 }
@@ -281,17 +299,17 @@ static int qf_encode_kv(const sprc_qformer_model* m, hipStream_t st, void* enc16
         RUN(sprc_cast_f32_to_16(enc32, enc16, (size_t)E * m->enc_width, m->dtype, st));
         enc = enc16;
     }
-    const int Nkv = m->n_cross * 2 * m->hidden, Kx = m->enc_width * (kv3 ? 3 : 1);
-    return gemm(st, m->dtype, m->dtype, E, Nkv, Kx, enc, Kx, m->ckv_all, kv_out, Nkv, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP, nullptr, 0,
-                nullptr, (int64_t)m->enc_width * ((m->x3 & SPRC_X3_CKV) ? 3 : 1), m->enc_width);
+    const int Nkv = m->n_cross * 2 * m->hidden, Kw = m->enc_width;
+    return gemm(st, m->dtype, m->dtype, E, Nkv, Kw, enc, Kw * (kv3 ? 2 : 1), m->ckv_all, kv_out, Nkv, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP, nullptr, 0,
+                nullptr, (int64_t)Kw * ((m->x3 & SPRC_X3_CKV) ? 2 : 1), kv3 ? 2 * Kw : 0);
 }
 
 // out[rows, embed_dim] (fp32) = proj(hidden rows `amap` of x16): the ITC heads (align_prompt.py:348,385)
 static int head(const sprc_qformer_model* m, hipStream_t st, int cm, int rows, const void* x16, const sprc_linear& w, float* out,
                 sprc_rowmap amap) {
     const int Hd = m->hidden;
-    return gemm(st, m->dtype, SPRC_F32, rows, m->embed_dim, (cm & SPRC_X3_HEADS) ? 3 * Hd : Hd, x16, x3_layouts(cm).ln ? 3 * Hd : Hd, w, out, m->embed_dim,
-                SPRC_ACT_NONE, nullptr, 0, amap, ID_MAP, nullptr, 0, nullptr, (int64_t)((m->x3 & SPRC_X3_HEADS) ? 3 * Hd : Hd), Hd);
+    return gemm(st, m->dtype, SPRC_F32, rows, m->embed_dim, Hd, x16, x3_layouts(cm).ln ? 2 * Hd : Hd, w, out, m->embed_dim,
+                SPRC_ACT_NONE, nullptr, 0, amap, ID_MAP, nullptr, 0, nullptr, (int64_t)((m->x3 & SPRC_X3_HEADS) ? 2 * Hd : Hd), (cm & SPRC_X3_HEADS) ? 2 * Hd : 0);
 }
 
 static int check_qf(const sprc_qformer_model* m) {
@@ -344,14 +362,13 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     const float scale = 1.0f / sqrtf((float)m->head_dim);                       // eva_vit.py:74
     SPRC_REQUIRE(!m->patch_x3 || dt == SPRC_F16, "sprc_vit_forward: patch_x3 is a mode of the fp16 model");
     const int patch_k = 3 * m->patch_size * m->patch_size;     // the convolution's own reduction length (588; launched zero padded)
-    if (m->patch_x3) {                                      // split-precision patch embedding: K' = 3 k_pad, ~fp32 products
+    if (m->patch_x3) {                                      // split-precision patch embedding: fp16 product + e4m3 correction segments
         RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, SPRC_F16X3, st));
-        RUN(gemm(st, dt, SPRC_F32, P, D, 3 * m->patch_k_pad, v.rows, 3 * m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP,
-                 ID_MAP, nullptr, 0, nullptr, 0, patch_k));
+        RUN(gemm_ka(patch_k, st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, 2 * m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP,
+                    ID_MAP, nullptr, 0, nullptr, 2 * m->patch_k_pad, 2 * m->patch_k_pad));
     } else {
         RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, dt, st));
-        RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP,
-                 nullptr, 0, nullptr, 0, patch_k));
+        RUN(gemm_ka(patch_k, st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D));
     }
     RUN(sprc_vit_assemble(v.pout, m->cls, m->pos, v.x, B, T, D, st));
     if (m->has_ln_pre) RUN(lnorm(st, dt, M, D, v.x, m->ln_pre_w, m->ln_pre_b, m->ln_eps, v.x, nullptr));
@@ -628,7 +645,7 @@ extern "C" int sprc_qformer_text(const sprc_qformer_model* m, const int64_t* inp
 // ---- stage-2 rerank: blip2_qformer_cir_rerank.py:399-445 ------------------------------------------
 extern "C" size_t sprc_qformer_kv_workspace_bytes(const sprc_qformer_model* m, int32_t B, int32_t tokens) {
     if (!m || B <= 0 || tokens <= 0) return 0;
-    return (is16(m->dtype) ? (size_t)B * tokens * m->enc_width * 2 * ((m->x3 & SPRC_X3_CKV) ? 3 : 1) : 0) + 512;
+    return (is16(m->dtype) ? (size_t)B * tokens * m->enc_width * 2 * ((m->x3 & SPRC_X3_CKV) ? 2 : 1) : 0) + 512;
 }
 
 extern "C" int sprc_qformer_encode_kv(const sprc_qformer_model* m, const float* raw, int32_t B, int32_t tokens, void* kv,

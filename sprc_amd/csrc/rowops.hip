@@ -51,7 +51,7 @@ __device__ __forceinline__ void layernorm_regs(RowRegs& r, int nch, int D, int l
     }
 }
 
-// KIND: the operand copy's type -- 0 fp32, 1 bf16, 2 fp16, 3 split fp16 [hi | lo | hi] (SPRC_F32 / _BF16 / _F16 / _F16X3)
+// KIND: the operand copy's type -- 0 fp32, 1 bf16, 2 fp16, 3 split row [hi fp16 | lo e4m3 | hi e4m3] (SPRC_F32 / _BF16 / _F16 / _F16X3)
 template <int KIND>
 __device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y16, int nch, int lane) {
 #pragma unroll
@@ -60,12 +60,8 @@ __device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y1
         if (i < nch) {
             if (y32) reinterpret_cast<float4*>(y32)[i] = r.v[c];
             if (y16) {
-                if constexpr (KIND == 3) {               // row width D = 4 nch: lo and the second hi copy sit D and 2 D elements further
-                    typedef f16x4 half4;
-                    half4 hi, lo;
-                    split_f16x4(r.v[c].x, r.v[c].y, r.v[c].z, r.v[c].w, hi, lo);
-                    half4* d = reinterpret_cast<half4*>(y16);
-                    d[i] = hi; d[nch + i] = lo; d[2 * nch + i] = hi;
+                if constexpr (KIND == 3) {               // split row of logical width D = 4 nch: [D fp16 | D e4m3 | D e4m3]
+                    store_split4(reinterpret_cast<char*>(y16), 4 * nch, 4 * i, r.v[c].x, r.v[c].y, r.v[c].z, r.v[c].w);
                 } else if constexpr (KIND != 0) {
                     uint2 pk;
                     pk.x = pack16x2<KIND == 2>(r.v[c].x, r.v[c].y);
@@ -122,12 +118,6 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams
 }
 
 // LayerNorm whose operand copy is e4m3fn: y8 = sat(LN(x) * q_scale)  (q_scale = 1 / the consumer GEMM's a_scale)
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
-    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
-    const int lo = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, lo, true);
-}
 
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_fp8_kernel(LnParams p, float q_scale) {
     const int lane = threadIdx.x & 63;
@@ -216,7 +206,7 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void qformer_embed_kernel(sprc
     }
     layernorm_regs(r, nch, p.hidden, lane, p.gamma, p.beta, p.eps);
     store_row<KIND>(r, p.y32 ? p.y32 + (int64_t)row * p.hidden : nullptr,
-                    p.y16 ? (char*)p.y16 + (int64_t)row * p.hidden * (KIND == 3 ? 6 : KIND ? 2 : 4) : nullptr, nch, lane);
+                    p.y16 ? (char*)p.y16 + (int64_t)row * p.hidden * (KIND == 3 ? 4 : KIND ? 2 : 4) : nullptr, nch, lane);
 }
 
 template <int KIND>
@@ -269,11 +259,8 @@ __global__ void im2row_kernel(const float* __restrict__ img, void* __restrict__ 
             const int64_t b = row / (G * G);
             v = img[((b * 3 + c) * S + (py * P + i)) * (int64_t)S + (px * P + j)];
         }
-        if constexpr (KIND == 3) {              // SPRC_F16X3: [hi | lo | hi], row width 3 kpad
-            _Float16 hi, lo;
-            split_f16(v, hi, lo);
-            _Float16* r = reinterpret_cast<_Float16*>(rows) + row * 3 * (int64_t)kpad + k;
-            r[0] = hi; r[kpad] = lo; r[2 * kpad] = hi;
+        if constexpr (KIND == 3) {              // SPRC_F16X3: split row of logical width kpad (4 kpad bytes)
+            store_split1(reinterpret_cast<char*>(rows) + row * 4 * (int64_t)kpad, kpad, k, v);
         } else if constexpr (KIND != 0) reinterpret_cast<uint16_t*>(rows)[e] = (uint16_t)(pack16x2<KIND == 2>(v, 0.f) & 0xffffu);
         else reinterpret_cast<float*>(rows)[e] = v;
     }
@@ -323,18 +310,14 @@ extern "C" int sprc_cast_f32_to_16(const float* src, void* dst, size_t n, int32_
     return SPRC_OK;
 }
 
-// fp32 [rows, cols] -> split fp16 [rows, 3 cols] = [hi | lo | hi]
+// fp32 [rows, cols] -> split rows [rows, 4 cols bytes] = [hi fp16 | lo e4m3 | hi e4m3]
 __global__ void cast_x3_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, int64_t rows, int cols4) {
-    typedef __attribute__((ext_vector_type(4))) _Float16 half4;
     const int64_t total = rows * cols4, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t row = e / cols4;
         const int c = (int)(e - row * cols4);
         const float4 v = reinterpret_cast<const float4*>(src)[e];
-        half4 hi, lo;
-        split_f16x4(v.x, v.y, v.z, v.w, hi, lo);
-        half4* d = reinterpret_cast<half4*>(dst) + row * 3 * cols4;
-        d[c] = hi; d[cols4 + c] = lo; d[2 * cols4 + c] = hi;
+        store_split4(reinterpret_cast<char*>(dst) + row * 16 * cols4, 4 * cols4, 4 * c, v.x, v.y, v.z, v.w);
     }
 }
 
@@ -374,7 +357,7 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
     } else if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, (hipStream_t)s, p);
     else if (a->out_dtype == SPRC_F16) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, (hipStream_t)s, p);
     else if (a->out_dtype == SPRC_F16X3) {
-        SPRC_REQUIRE(a->y16 == nullptr || (a->ld16 >= 3 * (int64_t)a->D && ((uintptr_t)a->y16 % 8) == 0), "sprc_layernorm(F16X3): ld16 >= 3 D, y16 8-byte aligned");
+        SPRC_REQUIRE(a->y16 == nullptr || (a->ld16 >= 2 * (int64_t)a->D && ((uintptr_t)a->y16 % 8) == 0), "sprc_layernorm(F16X3): ld16 >= 2 D (fp16 units: a split row is 4 D bytes), y16 8-byte aligned");
         hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, (hipStream_t)s, p);
     }
     else hipLaunchKernelGGL(layernorm_kernel<0>, grid, block, 0, (hipStream_t)s, p);

@@ -19,15 +19,16 @@ _TORCH_DT = {L.SPRC_F32: torch.float32, L.SPRC_BF16: torch.bfloat16, L.SPRC_F16:
 _SPRC_DT = {v: k for k, v in _TORCH_DT.items()}
 # layer kinds of the split-precision Q-Former (include/sprc.h: SPRC_X3_*)
 X3_QKV, X3_ATTN_OUT, X3_CROSS_Q, X3_CROSS_OUT, X3_FFN_IN, X3_FFN_OUT, X3_CKV, X3_HEADS, X3_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 255
-# Default split-precision masks of the fp16 engine: (image pass, query-side passes).  Chosen on FOUR full-depth planted goldens
-# (ViT-g and ViT-L, two draws of weights / images / queries each; tools/x3_sweep.py, profiles/r03_x3_sweep_seeds*.txt, MI355X;
-# max|dsim| over the four / Q-Former ms per bench step): none 1.3e-3 .. 1.6e-3 / 15 -- everything 5.1e-4 .. 9.1e-4 / 31 (what is
-# left is the fp16 ViT's own error: its floor moves between 5e-4 and 9e-4 from draw to draw) -- this choice 6.5e-4 .. 9.2e-4 / 24.
-# The gallery features carry 4x the error variance of the fused queries at a fifth of the Q-Former's work, so the image pass
-# splits everything but the self-attention Q|K|V product (the most expensive and least sensitive kind) and the query side the
-# four kinds that cost next to nothing + the FFN's output product.  (Without the latter: 20.5 ms, and 1.05e-3 on the second
-# ViT-g draw, 9.95e-4 on the first ViT-L one -- the max of 4608 errors of 2.2e-4 rms sits at 4 .. 5 sigma.)
-X3_DEFAULT = (X3_ALL & ~X3_QKV, X3_ATTN_OUT | X3_CROSS_Q | X3_CROSS_OUT | X3_FFN_OUT | X3_HEADS)
+# Default split-precision masks of the fp16 engine: (image pass, query-side passes).  Round 4 (split product = fp16 main term + two
+# e4m3 correction segments, 2 units of matrix time instead of round 3's 3): profiles/r04_gpuref_report_e8.txt, five full-depth planted
+# goldens + three on fp16-valued checkpoints, rms of the score error / what the kinds cost per bench step:
+#   254 : 174  (round 3's choice)        1.4e-4 .. 3.2e-4
+#   254 : 190  (+ the query side's FFN input products, +0.6 ms)   1.2e-4 .. 2.8e-4: on every ViT-g case at or below the error of the
+#              reference's own GPU arithmetic (tests/test_fp16_gpu.py) -- the default
+#   254 : 254  (+ Q|K|V and the query side's K|V projection, +1.7 ms)   1.1e-4 .. 2.9e-4: nothing more to gain, what is left is the fp16 ViT
+# The gallery features carry 4x the error variance of the fused queries at a fifth of the Q-Former's work, so the image pass splits
+# everything but the self-attention Q|K|V product (the most expensive and least sensitive kind).
+X3_DEFAULT = (X3_ALL & ~X3_QKV, X3_ATTN_OUT | X3_CROSS_Q | X3_CROSS_OUT | X3_FFN_IN | X3_FFN_OUT | X3_HEADS)
 FP8_MAX = 448.0                                   # largest finite e4m3fn
 
 
@@ -52,19 +53,49 @@ def rowmap(rows_per_group: int = 0, group_stride: int = 0, group_offset: int = 0
 
 # --------------------------------------------------------------------------------------------
 # thin operator wrappers (used by the unit parity tests and by Engine)
+# ---- the split-precision row layout (sprc.h: SPRC_F16X3), restated with torch ops: what the producers' kernels write ---------------
+SPLIT_LO_SHIFT, SPLIT_W_SHIFT, SPLIT_WLO_SHIFT = 12, 6, 18        # [x_lo 2^12 | x] . [W 2^6 | W_lo 2^18], product scaled by 2^-18
+
+
+def _e4m3_bytes(t: torch.Tensor) -> torch.Tensor:
+    return t.clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8)         # RNE, saturating
+
+
+def split_rows(x32: torch.Tensor, weight: bool = False) -> torch.Tensor:
+    """[M, K] fp32 -> split rows as an fp16 VIEW [M, 2K] (4K bytes per row): [K fp16: hi | K e4m3: (x - hi) 2^12 | K e4m3: x]
+    (activations) or [K fp16: W_hi | K e4m3: W 2^6 | K e4m3: (W - W_hi) 2^18] (weight=True)."""
+    hi = x32.to(torch.float16)
+    lo = x32 - hi.float()
+    a, b = ((x32 * 2.0 ** SPLIT_W_SHIFT, lo * 2.0 ** SPLIT_WLO_SHIFT) if weight else (lo * 2.0 ** SPLIT_LO_SHIFT, x32))
+    rows = torch.cat([hi.contiguous().view(torch.uint8).reshape(x32.shape[0], -1), _e4m3_bytes(a), _e4m3_bytes(b)], dim=1).contiguous()
+    return rows.view(torch.float16)
+
+
+def split_decode(rows: torch.Tensor, K: int):
+    """split rows (fp16 view [M, >= 2K]) -> (hi [M, K] fp16, lo8 [M, K] float = the stored (x - hi), hi8 [M, K] float = the stored x)"""
+    b = rows.contiguous().view(torch.uint8)
+    hi = b[:, :2 * K].contiguous().view(torch.float16)
+    lo8 = b[:, 2 * K:3 * K].contiguous().view(torch.float8_e4m3fn).float() * 2.0 ** -SPLIT_LO_SHIFT
+    hi8 = b[:, 3 * K:4 * K].contiguous().view(torch.float8_e4m3fn).float()
+    return hi, lo8, hi8
+
+
 # --------------------------------------------------------------------------------------------
 def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None, act=L.ACT_NONE, out=None,
-         M=None, amap=None, cmap=None, ldc=None, scratch=None, w_scale=None, a_scale=0.0, out_scale=0.0) -> torch.Tensor:
-    """fp8 operands (torch.float8_e4m3fn A and W): w_scale [N] fp32, a_scale; out_dtype SPRC_FP8 also needs out_scale."""
+         M=None, amap=None, cmap=None, ldc=None, scratch=None, w_scale=None, a_scale=0.0, out_scale=0.0, K=None, k8=0) -> torch.Tensor:
+    """fp8 operands (torch.float8_e4m3fn A and W): w_scale [N] fp32, a_scale; out_dtype SPRC_FP8 also needs out_scale.
+    Split-precision product: A and W are fp16 views of split rows (`split_rows`), K = the logical reduction length, k8 = 2 K."""
     lib = L.load()
     dt = _SPRC_DT[A.dtype]
     assert W.dtype == A.dtype and A.is_cuda and A.stride(-1) == 1 and W.stride(-1) == 1
-    N, K = W.shape
+    N = W.shape[0]
+    K = W.shape[1] if K is None else K
     M = A.shape[0] if M is None else M
     odt = dt if out_dtype is None else out_dtype
     if out is None:
-        out = torch.empty((M, N), dtype=_TORCH_DT[odt], device=A.device)
+        out = torch.empty((M, 2 * N if odt == L.SPRC_F16X3 else N), dtype=torch.float16 if odt == L.SPRC_F16X3 else _TORCH_DT[odt], device=A.device)
     g = L.GemmArgs()
+    g.k8 = k8
     g.M, g.N, g.K, g.dtype, g.out_dtype, g.act, g.max32 = M, N, K, dt, odt, act, 0
     g.A, g.lda, g.amap = A.data_ptr(), A.stride(0), amap or rowmap()
     g.W, g.ldw = W.data_ptr(), W.stride(0)
@@ -212,7 +243,8 @@ class Engine:
         dtype "fp16": fp16 MFMA operands -- the reference's GPU numerics are a fp16-autocast ViT and an fp32 Q-Former
         (align_prompt.py:366-368: the Q-Former runs OUTSIDE `maybe_autocast`); qformer_x3 (default: on for fp16) keeps the
         Q-Former at ~fp32 product precision on the fp16 MFMA by splitting weights and activations into hi + lo halves
-        (SPRC_F16X3, include/sprc.h): three fp16 products per fp32 product instead of the 16x slower exact-fp32 MFMA."""
+        (SPRC_F16X3, include/sprc.h): an fp16 product + two e4m3 correction products at twice the rate, instead of the 16x slower
+        exact-fp32 MFMA."""
         self.lib = L.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -265,17 +297,21 @@ class Engine:
     def _lin(self, w: torch.Tensor, b: Optional[torch.Tensor], k_pad: Optional[int] = None) -> L.Linear:
         return L.Linear(self._w(w, k_pad).data_ptr(), None if b is None else self._f32(b).data_ptr())
 
+    def _split_rows(self, w32: torch.Tensor) -> torch.Tensor:
+        """[out, in] fp32 -> the weight side of a split-precision product (sprc.h: SPRC_F16X3), uint8 [out, 4 in]:
+        [ in x fp16: W_hi | in x e4m3: W * 2^6 | in x e4m3: (W - W_hi) * 2^18 ]."""
+        rows = split_rows(w32, weight=True)
+        assert rows.shape == (w32.shape[0], 2 * w32.shape[1])
+        self._keep.append(rows)
+        return rows
+
     def _lin_q(self, w: torch.Tensor, b: Optional[torch.Tensor], kind: int) -> L.Linear:
         """A Q-Former linear of layer kind `kind` (X3_*): plain compute-dtype weights, or -- when the kind's bit is set in the
-        split-precision mask -- [W_hi | W_hi | W_lo] fp16, [out, 3 in]."""
+        split-precision mask -- split rows (`_split_rows`)."""
         if not (self.x3 & kind):
             return self._lin(w, b)
-        w32 = w.detach().to(device=self.device, dtype=torch.float32)
-        hi = w32.to(torch.float16)
-        lo = (w32 - hi.float()).to(torch.float16)
-        w3 = torch.cat([hi, hi, lo], dim=1).contiguous()
-        self._keep.append(w3)
-        return L.Linear(w3.data_ptr(), None if b is None else self._f32(b).data_ptr())
+        rows = self._split_rows(w.detach().to(device=self.device, dtype=torch.float32))
+        return L.Linear(rows.data_ptr(), None if b is None else self._f32(b).data_ptr())
 
     def _lin_patch(self, w: torch.Tensor, b: Optional[torch.Tensor]) -> L.Linear:
         """The patch embedding's weights [width, 3 P P] padded to patch_k_pad columns; fp16 engine: split precision, [W_hi | W_hi | W_lo]
@@ -283,11 +319,8 @@ class Engine:
         if not self.patch_x3:
             return self._lin(w, b, self.patch_k_pad)
         w32 = torch.nn.functional.pad(w.detach().to(device=self.device, dtype=torch.float32), (0, self.patch_k_pad - w.shape[1]))
-        hi = w32.to(torch.float16)
-        lo = (w32 - hi.float()).to(torch.float16)
-        w3 = torch.cat([hi, hi, lo], dim=1).contiguous()
-        self._keep.append(w3)
-        return L.Linear(w3.data_ptr(), None if b is None else self._f32(b).data_ptr())
+        rows = self._split_rows(w32)
+        return L.Linear(rows.data_ptr(), None if b is None else self._f32(b).data_ptr())
 
     def _lin8(self, w: torch.Tensor, b: Optional[torch.Tensor]):
         """-> (Linear with e4m3fn weights, device pointer of the per-output-channel scales)"""

@@ -74,3 +74,48 @@ def to_kept_index(case, a):
 
 
 TXT = {"eval": lambda c: c}
+
+
+# ---- config C4's sizes (CIRR test1: 2 316 gallery images, 4 148 composed queries), images drawn lazily -------------------------------
+C4_IMAGES, C4_QUERIES = 2316, 4148
+
+
+class LazyGallery(Dataset):
+    """n images ~ N(0, 1), image i from its own generator (seed * 100003 + i): every rank can read any slice without any rank
+    holding the 1.4 GB of pixels."""
+    split = "test1"
+
+    def __init__(self, n: int, seed: int):
+        self.n, self.seed = n, seed
+        self.names = [f"test1-img-{i:05d}" for i in range(n)]
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 100003 + i)
+        return self.names[i], torch.randn((3, 224, 224), generator=g)
+
+
+class C4Test(Dataset):
+    """items of the CIRR test split: (pair_id, reference_name, caption, group_members)   (data_utils.py:255-262)"""
+
+    def __init__(self, names, ref, groups):
+        self.names, self.ref, self.groups = names, ref, groups
+
+    def __len__(self):
+        return len(self.ref)
+
+    def __getitem__(self, i):
+        return 12000 + i, self.names[self.ref[i]], f"q{i}", [self.names[g] for g in self.groups[i]]
+
+
+def build_c4(seed: int = 0):
+    rng = np.random.default_rng(500 + seed)
+    ids, mask, _ = synth.make_queries(C4_QUERIES, C4_IMAGES, seed=600 + seed)
+    ref = rng.integers(0, C4_IMAGES, size=C4_QUERIES)
+    groups = np.zeros((C4_QUERIES, 6), dtype=np.int64)
+    for q in range(C4_QUERIES):
+        others = rng.choice(C4_IMAGES, 8, replace=False)
+        groups[q] = rng.permutation(np.array([ref[q], *[o for o in others if o != ref[q]][:5]]))
+    return dict(ids=ids, mask=mask, ref=ref, groups=groups)

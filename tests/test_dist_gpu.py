@@ -41,14 +41,19 @@ def _model(case):
     return model
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend="gloo"):
+    """backend "gloo": all ranks share cuda:0 (the 1-GPU box); "nccl": one rank per device over RCCL (a box with >= `world` GPUs)."""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = f"cuda:{rank}" if backend == "nccl" else DEV
+    torch.cuda.set_device(torch.device(dev))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from sprc_amd import dist_eval as DE
     from sprc_amd import engine as E
     case = DC.build(0)
-    model = _model(case)
+    model = _model(case).to(dev)
     gallery = DC.Gallery(case["images"])
     rel = DC.Relative(case["ref"], case["tgt"], case["groups"])
     rec = {}
@@ -78,13 +83,13 @@ def _free_port():
     return p
 
 
-def test_two_ranks_on_one_gpu_equal_the_single_process_harness():
+def _two_rank_check(backend):
     from sprc_amd import engine as E
     from sprc_amd import harness as H
     world = 2
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), out, backend), nprocs=world, join=True)
         res = {r: dict(out[r]) for r in range(world)}
     case = DC.build(0)
     model = _model(case)
@@ -106,6 +111,68 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_harness():
         assert res[r]["cirr"] == want_cirr
         assert res[r]["top"] == want_top and res[r]["sub"] == want_sub
         assert res[r]["n_raw"] < res[r]["n_local"]            # raw embeddings only for local reference images
+
+
+def test_two_ranks_on_one_gpu_equal_the_single_process_harness():
+    _two_rank_check("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device (the test box has one; "
+                    "the first box with two proves N > 1 over RCCL -- until then N > 1 over RCCL is UNMEASURED)")
+def test_two_rccl_ranks_one_per_gpu_equal_the_single_process_harness():
+    """VERDICT r3 missing #2 / item 6(a): TWO ranks over RCCL, one per device -- both all_gather_into_tensor exchanges on device
+    memory across xGMI, owner-routed fusion, the k x R merge -- against the single-process harness: score bits, top-51, metrics,
+    submission dicts."""
+    _two_rank_check("nccl")
+
+
+def _c4_worker(rank, world, port, out, depth):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sprc_amd import dist_eval as DE
+    case = DC.build_c4(0)
+    model = _c4_model(case, depth)
+    gallery = DC.LazyGallery(DC.C4_IMAGES, seed=7)
+    top, sub = DE.generate_cirr_test_dicts_sharded(DC.C4Test(gallery.names, case["ref"], case["groups"]), gallery, model, DC.TXT,
+                                                   num_workers=0, gallery_batch_size=64)
+    torch.cuda.synchronize()
+    out[rank] = dict(top=top, sub=sub)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _c4_model(case, depth):
+    from sprc_amd.model import Blip2QformerCirAlignPrompt
+    cfg = get_config("pretrain", vit_depth=depth)
+    model = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=64)
+    assert not model.load_state_dict(synth.make_state_dict(cfg, seed=12), strict=False).missing_keys
+    model = model.to(DEV)
+    model.tokenizer = DC.FakeTokenizer(case["ids"], case["mask"])
+    return model
+
+
+def test_c4_sizes_eight_ranks_sharing_the_gpu_equal_the_single_process_submission():
+    """BASELINE config C4 at its REAL sizes -- CIRR test1: 2 316 gallery images, 4 148 composed queries, the gallery in 8 shards -- through
+    `generate_cirr_test_dicts_sharded` (cirr_test_submission.py:61-132) with eight ranks that share the box's one GPU (gloo staging: a
+    plumbing run, not a scaling number; ViT truncated to one block to bound time, the full Q-Former): ragged shards (2316 = 8 x 289 + 4),
+    owner-routed fusion with unequal per-rank query counts, both exchanges, the 8 x 51-candidate merge.  The two submission dicts (top-50
+    names, subset top-3) of every rank must equal the single-process harness's, entry for entry."""
+    from sprc_amd import harness as H
+    world, depth = 8, 1
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_c4_worker, args=(world, _free_port(), out, depth), nprocs=world, join=True)
+        res = {r: dict(out[r]) for r in range(world)}
+    case = DC.build_c4(0)
+    model = _c4_model(case, depth)
+    gallery = DC.LazyGallery(DC.C4_IMAGES, seed=7)
+    (feats, raw), names = H.extract_index_blip_features(gallery, model, batch_size=64, num_workers=0)
+    assert len(names) == DC.C4_IMAGES
+    want_top, want_sub = H.generate_cirr_test_dicts(DC.C4Test(gallery.names, case["ref"], case["groups"]), model, (feats, raw), names, DC.TXT)
+    assert len(want_top) == DC.C4_QUERIES and all(len(v) == 50 for v in want_top.values()) and all(len(v) == 3 for v in want_sub.values())
+    for r in range(world):
+        assert res[r]["top"] == want_top and res[r]["sub"] == want_sub, f"rank {r}"
 
 
 def test_bench_gpus2_spawns_two_ranks():
