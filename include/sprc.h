@@ -183,6 +183,10 @@ typedef struct {
     const void* v2; int64_t ldv2;
     int32_t Tk2;
     const int32_t* kv_index; const int32_t* kv2_index;
+    /* Training (dtype SPRC_F32 only): dropout on the attention probabilities (Qformer.py:264), out = (D o softmax(..)) V with
+     * D[b, h, i, j] = sprc_dropout keep mask at element index ((b H + h) Tq + i) Tk + j of site `drop_site`, scaled 1 / (1 - drop_p).
+     * drop_p == 0: none (inference). */
+    float drop_p; uint32_t drop_site; uint64_t drop_seed;
     int32_t out_x3;   /* dtype SPRC_F16 only: `out` rows are stored in the SPRC_F16X3 layout (logical width H * head_dim, ldo >= 2 H head_dim) */
 } sprc_attention_args;
 int sprc_attention(const sprc_attention_args* a, sprc_stream s);
@@ -430,7 +434,14 @@ typedef struct {
     const float* key_mask; float scale;
     float *dq, *dk, *dv; int64_t lddq, lddk, lddv;
     void* scratch; size_t scratch_bytes;
+    float drop_p; uint32_t drop_site; uint64_t drop_seed;      /* the forward call's attention-probability dropout (0: none) */
 } sprc_attention_bwd_args;
+/* Dropout as the reference trains with it (nn.Dropout(p) at Qformer.py:113,264,293,379; blip_fine_tune_2.py:290 `.train()`):
+ *   y[i] = keep(seed, site, i) ? x[i] / (1 - p) : 0      (+ resid[i] when resid != NULL: the post-dropout residual add of :294,380)
+ * keep is a COUNTER-BASED mask -- z = seed + site * 0x9E3779B97F4A7C15 + i * 0xD1B54A32D192ED03 (mod 2^64), SplitMix64 finaliser,
+ * keep <=> (z >> 32) >= floor(p * 2^32) -- so backward regenerates it (dx = sprc_dropout_f32(dy)) instead of storing it, and a CPU
+ * restatement (oracle/sprc_oracle.py: drop_keep) injects the SAME masks into the reference for the gradient goldens.  x may alias y. */
+int sprc_dropout_f32(const float* x, const float* resid, float* y, size_t n, uint64_t seed, uint32_t site, float p, sprc_stream s);
 int sprc_attention_bwd(const sprc_attention_bwd_args* a, sprc_stream s);
 /* The rows sprc_qformer_embed normalises, WITHOUT the LayerNorm (pre [B, Lq+Lt, hidden]), and the scatter of their gradient:
  * dquery[b * dq_bstride + row] += (dq_bstride 0: summed over the batch), dword[id] +=, dpos[position] += (atomic adds). */

@@ -17,6 +17,7 @@ Files written:
   tests/golden/planted_full_eva.npz  the same at FULL depth (39 blocks), 96 gallery x 48 queries (--full): the case the
                                16-bit engines are held to max|dsim| < 1e-3 on
   tests/golden/train_eva.npz   training forward: the reference's three losses (loss_itc, loss_rtc, loss_align) on 5 triplets
+  tests/golden/train_dropout_eva.npz  the same in TRAIN mode (Q-Former dropout p = 0.1 as blip_fine_tune_2.py:290 runs it), masks injected
   tests/golden/rerank_eva.npz  stage-2 rerank: the reference's Blip2QformerCirRerank.inference_rerank on 3 queries x 4 candidates
   tests/golden/metrics.json    reference compute_cirr_val_metrics / compute_fiq_val_metrics /
                                generate_cirr_test_dicts on synthetic sims (with engineered ties)
@@ -330,23 +331,84 @@ def grad_functionals(name: str, g: torch.Tensor) -> np.ndarray:
     return np.concatenate([[float(flat.norm())], (r @ flat).numpy(), [float(flat.sum())], flat[probe].numpy()])
 
 
-def train_goldens(out: Path, seed: int = 4):
+class _InjectedDropout(torch.nn.Module):
+    """Stands in for ONE nn.Dropout instance of the reference's Q-Former in train mode: the same arithmetic (x * keep / (1 - p)) with
+    the keep mask of oracle.sprc_oracle.drop_keep -- a counter-based hash both the HIP kernels and the oracle regenerate -- instead of
+    a draw from torch's global generator.  `state` carries the effective seed and the running pass number (one bert.forward = one pass)."""
+
+    def __init__(self, state: dict, layer: int, kind: int):
+        super().__init__()
+        self.state, self.layer, self.kind = state, layer, kind
+
+    def forward(self, x):
+        from oracle import sprc_oracle as O
+        if not self.training:
+            return x
+        site = O.drop_site(self.state["pass"], self.layer, self.kind)
+        self.state["calls"].append(site)
+        keep = torch.from_numpy(O.drop_keep(self.state["seed"], site, x.numel(), self.state["p"])).view(x.shape)
+        return x * keep.to(x.dtype) * (1.0 / (1.0 - self.state["p"]))
+
+
+def inject_dropout_masks(model, seed: int, p: float) -> dict:
+    """Replace every nn.Dropout of model.Qformer.bert (Qformer.py:75,158,288,374: embeddings, attention probabilities, BertSelfOutput,
+    BertOutput) by an `_InjectedDropout` numbered as oracle.drop_site numbers them; a forward pre-hook on bert counts the passes."""
+    from oracle import sprc_oracle as O
+    bert = model.Qformer.bert
+    state = {"seed": seed, "p": p, "pass": -1, "calls": []}
+    assert isinstance(bert.embeddings.dropout, torch.nn.Dropout) and abs(bert.embeddings.dropout.p - p) < 1e-12
+    bert.embeddings.dropout = _InjectedDropout(state, 0, O.DROP_EMB)
+    for l, layer in enumerate(bert.encoder.layer):
+        layer.attention.self.dropout = _InjectedDropout(state, l, O.DROP_SELF_P)
+        layer.attention.output.dropout = _InjectedDropout(state, l, O.DROP_SELF_OUT)
+        if getattr(layer, "has_cross_attention", False):
+            layer.crossattention.self.dropout = _InjectedDropout(state, l, O.DROP_CROSS_P)
+            layer.crossattention.output.dropout = _InjectedDropout(state, l, O.DROP_CROSS_OUT)
+        layer.output.dropout = _InjectedDropout(state, l, O.DROP_FFN_T)
+        layer.output_query.dropout = _InjectedDropout(state, l, O.DROP_FFN_Q)
+    left = [n for n, m in bert.named_modules() if isinstance(m, torch.nn.Dropout)]
+    assert not left, f"un-injected dropout modules: {left}"
+    bert.register_forward_pre_hook(lambda m, a: state.__setitem__("pass", state["pass"] + 1))
+    return state
+
+
+DROPOUT_SEED, DROPOUT_P = 7, 0.1                    # model.dropout_seed of the dropout golden; BERT's hidden / attention dropout (blip2.py:48)
+
+
+def effective_drop_seed(dropout_seed: int, step: int = 1) -> int:
+    """the 64-bit seed sprc_amd.model gives the masks of training step `step` (model.py: _TrainFn.forward)"""
+    return (dropout_seed * 0x9E3779B1 + step) & 0xFFFFFFFFFFFFFFFF
+
+
+def train_goldens(out: Path, seed: int = 4, dropout: bool = False):
     """Training forward + backward (N4): the REFERENCE's Blip2QformerCirAlignPrompt.forward (align_prompt.py:95-200) in eval mode on 5
     (reference, target, caption) triplets, depth-2 ViT-g + the full Q-Former: the three losses, and the gradient of
     loss_itc + 0.4 loss_rtc + 0.4 loss_align (blip_fine_tune_2.py:293-304) with respect to every trainable tensor, as
     `grad_functionals`; tensors the reference leaves without a gradient (itm_head, the LM head) are listed."""
     cfg = get_config("pretrain", vit_depth=2)
     sd = synth.make_state_dict(cfg, seed=seed)
-    model = ref_import.build_reference_model(cfg, sd)
+    # dropout=True: the reference AS IT TRAINS (blip_fine_tune_2.py:290 `blip_model.train()`: Q-Former dropout p = 0.1 active, the ViT
+    # pinned to eval by align_prompt.py:67-68) with the masks injected (`inject_dropout_masks`); False: eval mode
+    model = ref_import.build_reference_model(cfg, sd, eval_mode=not dropout)
     B = 5
     images = synth.make_images(2 * B, seed=seed)
     ids, mask, _ = synth.make_queries(B, B, seed=seed + 1)
+    state = None
+    if dropout:
+        assert model.training and model.Qformer.training and not model.visual_encoder.training
+        state = inject_dropout_masks(model, effective_drop_seed(DROPOUT_SEED), DROPOUT_P)
     model.tokenizer.set_next(ids, mask)
     with torch.no_grad():
         out_d = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
+    if state is not None:                                   # the second evaluation below must draw the same masks
+        n_sites = len(state["calls"])
+        assert state["pass"] == 3 and n_sites == len(set(state["calls"]))
+        state["pass"], state["calls"] = -1, []
     model.tokenizer.set_next(ids, mask)
     model.zero_grad()
     losses = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
+    if state is not None:
+        assert all(abs(float(losses[k]) - float(out_d[k])) < 1e-6 for k in losses), "the injected masks are not reproducible"
     total = sum(GRAD_WEIGHTS[k] * v for k, v in losses.items())
     total.backward()
     grads, no_grad, frozen = {}, [], []
@@ -364,6 +426,9 @@ def train_goldens(out: Path, seed: int = 4):
                         input_ids=ids.numpy(), attention_mask=mask.numpy(),
                         grad_names=np.array(list(grads)), grad_values=np.stack(list(grads.values())),
                         no_grad_names=np.array(no_grad), grad_weights=json.dumps(GRAD_WEIGHTS),
+                        dropout_p=np.float64(DROPOUT_P if dropout else 0.0), dropout_seed=np.int64(DROPOUT_SEED if dropout else 0),
+                        drop_seed_effective=np.uint64(effective_drop_seed(DROPOUT_SEED) if dropout else 0),
+                        dropout_sites=np.int64(n_sites if dropout else 0),
                         **{k: np.float64(v.item()) for k, v in out_d.items()})
     print(f"wrote {out}:", {k: round(v.item(), 6) for k, v in out_d.items()}, f"{len(grads)} gradient tensors, no grad: {no_grad[:6]} ...")
 
@@ -425,6 +490,8 @@ def main():
         model_goldens("pretrain_vitL", 2, n_img=3, n_q=4, out=GOLD / "tiny_clip.npz")
     if want("train"):
         train_goldens(GOLD / "train_eva.npz")
+    if want("train_dropout"):                   # the reference as it trains: Q-Former dropout p = 0.1 on, reproducible injected masks
+        train_goldens(GOLD / "train_dropout_eva.npz", dropout=True)
     if want("rerank"):
         rerank_goldens(GOLD / "rerank_eva.npz")
     if want("planted"):

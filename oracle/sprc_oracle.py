@@ -129,9 +129,42 @@ def encode_image_tokens(sd: SD, cfg, image: Tensor, taps: Optional[dict] = None)
 # --------------------------------------------------------------------------------------
 # R5: Q-Former  (lavis/models/blip2_models/Qformer.py)
 # --------------------------------------------------------------------------------------
+# ---- training-mode dropout (Qformer.py:113,264,293,379 under blip_fine_tune_2.py:290 `.train()`) with REPRODUCIBLE masks ----------------
+# nn.Dropout draws from torch's global generator; a golden needs masks both sides can regenerate.  The mask of element i of dropout
+# site `site` under `seed` is a counter-based hash (the same integer arithmetic as csrc/common.hpp: drop_keep), injected into the
+# reference by oracle/gen_golden.py and regenerated by the HIP kernels.
+DROP_SELF_P, DROP_SELF_OUT, DROP_CROSS_P, DROP_CROSS_OUT, DROP_FFN_Q, DROP_FFN_T, DROP_EMB = 0, 1, 2, 3, 4, 5, 255
+
+
+def drop_site(pass_id: int, layer: int, kind: int) -> int:
+    """site id of a dropout call: pass 0 = fusion pass 1, 1 = pass 2, 2 = target-image pass, 3 = text-only prompt pass (the order of
+    align_prompt.py:120-179); kind = DROP_*; the embedding dropout of a pass is (pass, 0, DROP_EMB)."""
+    return pass_id * 256 + (DROP_EMB if kind == DROP_EMB else layer * 8 + kind)
+
+
+def drop_keep(seed: int, site: int, n: int, p: float) -> np.ndarray:
+    """keep mask [n] (bool) of dropout site `site`: z = seed + site * 0x9E3779B97F4A7C15 + i * 0xD1B54A32D192ED03 (mod 2^64),
+    SplitMix64 finaliser, keep <=> (z >> 32) >= floor(p * 2^32)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed % (1 << 64)) + np.uint64(site) * np.uint64(0x9E3779B97F4A7C15) + np.arange(n, dtype=np.uint64) * np.uint64(0xD1B54A32D192ED03)
+        z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return (z >> np.uint64(32)) >= np.uint64(int(p * 4294967296.0))
+
+
+def dropout(x: Tensor, drop, site: int) -> Tensor:
+    """x * keep / (1 - p) with the reproducible mask; drop = None (eval) or (seed, p, pass_id)."""
+    if drop is None or drop[1] <= 0.0:
+        return x
+    seed, p = drop[0], drop[1]
+    keep = torch.from_numpy(drop_keep(seed, site, x.numel(), p)).view(x.shape)
+    return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+
+
 def _bert_attention(sd: SD, pre: str, x_q: Tensor, x_kv: Tensor, add_mask: Optional[Tensor],
-                    heads: int, eps: float) -> Tensor:
-    """BertSelfAttention.forward Qformer.py:175-281 + BertSelfOutput :291-295 (eval: dropout = identity)."""
+                    heads: int, eps: float, drop=None, layer: int = 0, cross: bool = False) -> Tensor:
+    """BertSelfAttention.forward Qformer.py:175-281 + BertSelfOutput :291-295 (drop None = eval: dropout = identity)."""
     B, Sq, Hd = x_q.shape
     dh = Hd // heads
     q = F.linear(x_q, sd[pre + "self.query.weight"].float(), sd[pre + "self.query.bias"].float())
@@ -144,21 +177,27 @@ def _bert_attention(sd: SD, pre: str, x_q: Tensor, x_kv: Tensor, add_mask: Optio
     if add_mask is not None:
         s = s + add_mask                                                     # :253
     pr = torch.softmax(s, dim=-1)
+    if drop is not None:
+        pr = dropout(pr, drop, drop_site(drop[2], layer, DROP_CROSS_P if cross else DROP_SELF_P))            # :264
     ctx = torch.matmul(pr, v).permute(0, 2, 1, 3).contiguous().view(B, Sq, Hd)
     out = F.linear(ctx, sd[pre + "output.dense.weight"].float(), sd[pre + "output.dense.bias"].float())
+    if drop is not None:
+        out = dropout(out, drop, drop_site(drop[2], layer, DROP_CROSS_OUT if cross else DROP_SELF_OUT))      # :293
     return _ln(out + x_q, sd[pre + "output.LayerNorm.weight"], sd[pre + "output.LayerNorm.bias"], eps)
 
 
-def _bert_ffn(sd: SD, pre_i: str, pre_o: str, x: Tensor, eps: float) -> Tensor:
-    """feed_forward_chunk(_query) Qformer.py:482-490: LN(W2 . GELU_erf(W1 x) + x)."""
+def _bert_ffn(sd: SD, pre_i: str, pre_o: str, x: Tensor, eps: float, drop=None, layer: int = 0, query: bool = False) -> Tensor:
+    """feed_forward_chunk(_query) Qformer.py:482-490: LN(dropout(W2 . GELU_erf(W1 x)) + x)."""
     h = F.gelu(F.linear(x, sd[pre_i + "dense.weight"].float(), sd[pre_i + "dense.bias"].float()))
     h = F.linear(h, sd[pre_o + "dense.weight"].float(), sd[pre_o + "dense.bias"].float())
+    if drop is not None:
+        h = dropout(h, drop, drop_site(drop[2], layer, DROP_FFN_Q if query else DROP_FFN_T))                 # :379
     return _ln(h + x, sd[pre_o + "LayerNorm.weight"], sd[pre_o + "LayerNorm.bias"], eps)
 
 
 def qformer_forward(sd: SD, cfg, query_embeds: Tensor, input_ids: Optional[Tensor] = None,
                     attention_mask: Optional[Tensor] = None, encoder_hidden_states: Optional[Tensor] = None,
-                    taps: Optional[dict] = None) -> Tensor:
+                    taps: Optional[dict] = None, drop=None) -> Tensor:
     """`BertModel.forward` Qformer.py:810-973 in the three call shapes of the retrieval path.
 
     (i)  image-only: input_ids None, encoder_hidden_states given  (align_prompt.py:376-381)
@@ -179,6 +218,8 @@ def qformer_forward(sd: SD, cfg, query_embeds: Tensor, input_ids: Optional[Tenso
     else:
         emb = query_embeds.float()
     x = _ln(emb, sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], qc.ln_eps)
+    if drop is not None:
+        x = dropout(x, drop, drop_site(drop[2], 0, DROP_EMB))                                                # :113
     B, S_all, _ = x.shape
     if attention_mask is None:
         attention_mask = torch.ones((B, S_all))                              # :887-890
@@ -187,19 +228,19 @@ def qformer_forward(sd: SD, cfg, query_embeds: Tensor, input_ids: Optional[Tenso
         taps["emb"] = x.clone()
     for l in range(qc.layers):
         b = f"{p}encoder.layer.{l}."
-        a = _bert_attention(sd, b + "attention.", x, x, add_mask, qc.heads, qc.ln_eps)
+        a = _bert_attention(sd, b + "attention.", x, x, add_mask, qc.heads, qc.ln_eps, drop, l)
         if encoder_hidden_states is not None:                                # :434
             qa = a[:, :Lq, :]
             if l % qc.cross_freq == 0:                                       # :392-399, :438-450
                 # encoder mask is all ones -> additive 0 (:925-934)
                 qa = _bert_attention(sd, b + "crossattention.", qa, encoder_hidden_states.float(), None,
-                                     qc.heads, qc.ln_eps)
-            out = _bert_ffn(sd, b + "intermediate_query.", b + "output_query.", qa, qc.ln_eps)
+                                     qc.heads, qc.ln_eps, drop, l, cross=True)
+            out = _bert_ffn(sd, b + "intermediate_query.", b + "output_query.", qa, qc.ln_eps, drop, l, query=True)
             if a.shape[1] > Lq:                                              # :461-468
-                out_t = _bert_ffn(sd, b + "intermediate.", b + "output.", a[:, Lq:, :], qc.ln_eps)
+                out_t = _bert_ffn(sd, b + "intermediate.", b + "output.", a[:, Lq:, :], qc.ln_eps, drop, l)
                 out = torch.cat([out, out_t], dim=1)
         else:                                                                # :469-475
-            out = _bert_ffn(sd, b + "intermediate.", b + "output.", a, qc.ln_eps)
+            out = _bert_ffn(sd, b + "intermediate.", b + "output.", a, qc.ln_eps, drop, l)
         x = out
         if taps is not None and l == 0:
             taps["layer0"] = x.clone()
@@ -213,11 +254,11 @@ def _normalize(x: Tensor) -> Tensor:
     return F.normalize(x, dim=-1)                                            # x / max(||x||, 1e-12)
 
 
-def extract_target_features(sd: SD, cfg, image: Tensor, taps: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+def extract_target_features(sd: SD, cfg, image: Tensor, taps: Optional[dict] = None, drop=None) -> Tuple[Tensor, Tensor]:
     """`Blip2QformerCirAlignPrompt.extract_target_features` align_prompt.py:364-386 (CPU path: all fp32)."""
     raw = encode_image_tokens(sd, cfg, image, taps=taps)
     B = raw.shape[0]
-    q = qformer_forward(sd, cfg, sd["query_tokens"].float().expand(B, -1, -1), encoder_hidden_states=raw)
+    q = qformer_forward(sd, cfg, sd["query_tokens"].float().expand(B, -1, -1), encoder_hidden_states=raw, drop=drop)
     feats = _normalize(F.linear(q, sd["vision_proj.weight"].float(), sd["vision_proj.bias"].float()))
     return feats, raw
 
@@ -275,7 +316,7 @@ def inference_rerank_stage1(sd: SD, cfg, target_feats: Tensor, input_ids: Tensor
     return similarity(text_feature(sd, cfg, input_ids, attention_mask), target_feats)
 
 
-def qformer_text_only(sd: SD, cfg, prompt_embeds: Tensor, input_ids: Tensor, attention_mask: Tensor) -> Tensor:
+def qformer_text_only(sd: SD, cfg, prompt_embeds: Tensor, input_ids: Tensor, attention_mask: Tensor, drop=None) -> Tensor:
     """`BertModel.forward(..., no_img=True)` (Qformer.py:88-104, used by align_prompt.py:173-179): the embedding rows are
     [text[0] ([CLS]) ; the 32 prompt rows ; text[1:]], EVERY row gets its absolute position (0..63), one LayerNorm; no
     encoder states -> no cross-attention, text FFN on all rows.  attention_mask [B,64] is used as given."""
@@ -285,32 +326,37 @@ def qformer_text_only(sd: SD, cfg, prompt_embeds: Tensor, input_ids: Tensor, att
     emb = torch.cat([we[:, :1, :], prompt_embeds.float(), we[:, 1:, :]], dim=1)
     emb = emb + sd[p + "embeddings.position_embeddings.weight"].float()[:emb.shape[1]].unsqueeze(0)
     x = _ln(emb, sd[p + "embeddings.LayerNorm.weight"], sd[p + "embeddings.LayerNorm.bias"], qc.ln_eps)
+    if drop is not None:
+        x = dropout(x, drop, drop_site(drop[2], 0, DROP_EMB))
     add_mask = (1.0 - attention_mask[:, None, None, :].float()) * -10000.0
     for l in range(qc.layers):
         b = f"{p}encoder.layer.{l}."
-        a = _bert_attention(sd, b + "attention.", x, x, add_mask, qc.heads, qc.ln_eps)
-        x = _bert_ffn(sd, b + "intermediate.", b + "output.", a, qc.ln_eps)
+        a = _bert_attention(sd, b + "attention.", x, x, add_mask, qc.heads, qc.ln_eps, drop, l)
+        x = _bert_ffn(sd, b + "intermediate.", b + "output.", a, qc.ln_eps, drop, l)
     return x
 
 
-def training_losses(sd: SD, cfg, image: Tensor, target: Tensor, input_ids: Tensor, attention_mask: Tensor) -> Dict[str, Tensor]:
-    """`Blip2QformerCirAlignPrompt.forward` align_prompt.py:95-200 in eval mode (dropout = identity), pre-tokenised text:
-    loss_itc (fusion -> target contrastive), loss_rtc (text-only prompt -> target contrastive), loss_align (MSE between
-    the mean fused query token and the mean prompt token)."""
+def training_losses(sd: SD, cfg, image: Tensor, target: Tensor, input_ids: Tensor, attention_mask: Tensor,
+                    drop: Optional[Tuple[int, float]] = None) -> Dict[str, Tensor]:
+    """`Blip2QformerCirAlignPrompt.forward` align_prompt.py:95-200, pre-tokenised text: loss_itc (fusion -> target contrastive),
+    loss_rtc (text-only prompt -> target contrastive), loss_align (MSE between the mean fused query token and the mean prompt token).
+    drop None: eval mode (dropout = identity); drop = (seed, p): train mode as blip_fine_tune_2.py:290 runs it, the Q-Former's dropout
+    (p = 0.1 in the reference) with the reproducible masks of `drop_keep` (the ViT stays in eval: align_prompt.py:67-68)."""
+    dr = (lambda pass_id: None) if drop is None else (lambda pass_id: (drop[0], drop[1], pass_id))
     B = image.shape[0]
     Lq = cfg.qformer.num_query
     temp = sd["temp"].float() if "temp" in sd else torch.tensor(0.07)
     raw = encode_image_tokens(sd, cfg, image)
     qt = sd["query_tokens"].float().expand(B, -1, -1)
     mask = torch.cat([torch.ones((B, Lq), dtype=attention_mask.dtype), attention_mask], dim=1)
-    p1 = qformer_forward(sd, cfg, qt, input_ids, mask, encoder_hidden_states=raw)             # :120-127
-    p2 = qformer_forward(sd, cfg, p1[:, :Lq, :], input_ids, mask)                             # :129-134
+    p1 = qformer_forward(sd, cfg, qt, input_ids, mask, encoder_hidden_states=raw, drop=dr(0))             # :120-127
+    p2 = qformer_forward(sd, cfg, p1[:, :Lq, :], input_ids, mask, drop=dr(1))                             # :129-134
     fusion = _normalize(F.linear(p2[:, 32, :], sd["text_proj.weight"].float(), sd["text_proj.bias"].float()))
-    target_feats, _ = extract_target_features(sd, cfg, target)                                # :141-155
+    target_feats, _ = extract_target_features(sd, cfg, target, drop=dr(2))                    # :141-155
     targets = torch.arange(B)
     loss_itc = F.cross_entropy(similarity(fusion, target_feats) / temp, targets)              # :157-167
     prompt = sd["prompt_tokens"].float().expand(B, -1, -1)
-    t_only = qformer_text_only(sd, cfg, prompt, input_ids, mask)                              # :170-179
+    t_only = qformer_text_only(sd, cfg, prompt, input_ids, mask, drop=dr(3))                  # :170-179
     t_feat = _normalize(F.linear(t_only[:, 0, :], sd["text_proj.weight"].float(), sd["text_proj.bias"].float()))
     loss_rtc = F.cross_entropy(similarity(t_feat, target_feats) / temp, targets)              # :181-190
     loss_align = F.mse_loss(p1[:, :Lq, :].mean(1), prompt.clone().detach().mean(1))           # :192-193 (the prompt side is detached)
@@ -321,14 +367,14 @@ TRAIN_LOSS_WEIGHTS = {"loss_itc": 1.0, "loss_rtc": 0.4, "loss_align": 0.4}    # 
 
 
 def training_gradients(sd: SD, cfg, image: Tensor, target: Tensor, input_ids: Tensor, attention_mask: Tensor,
-                       weights: Optional[Dict[str, float]] = None) -> Tuple[Dict[str, Tensor], Dict[str, Tensor]]:
+                       weights: Optional[Dict[str, float]] = None, drop: Optional[Tuple[int, float]] = None) -> Tuple[Dict[str, Tensor], Dict[str, Tensor]]:
     """-> (losses, {name: d(loss_itc + w_rtc loss_rtc + w_align loss_align) / d tensor}) for every tensor the reference trains
     (blip_fine_tune_2.py:257-262: everything with requires_grad, i.e. all but the ViT trunk, align_prompt.py:64-69): torch autograd
     over `training_losses`, the restatement of `forward` above.  Tensors `forward` does not touch (itm_head, the LM head) get none."""
     weights = weights or TRAIN_LOSS_WEIGHTS
     leaf = {k: (v.detach().float().clone().requires_grad_(not k.startswith("visual_encoder.")) if v.is_floating_point() else v)
             for k, v in sd.items()}
-    losses = training_losses(leaf, cfg, image, target, input_ids, attention_mask)
+    losses = training_losses(leaf, cfg, image, target, input_ids, attention_mask, drop=drop)
     total = sum(weights[k] * v for k, v in losses.items())
     total.backward()
     grads = {k: v.grad for k, v in leaf.items() if torch.is_tensor(v) and v.is_floating_point() and v.grad is not None}

@@ -52,7 +52,7 @@ class AttentionArgs(C.Structure):
                 ("q", vp), ("ldq", i64), ("k", vp), ("ldk", i64), ("v", vp), ("ldv", i64), ("out", vp), ("ldo", i64),
                 ("key_mask", vp), ("scale", f32),
                 ("k2", vp), ("ldk2", i64), ("v2", vp), ("ldv2", i64), ("Tk2", i32), ("kv_index", vp), ("kv2_index", vp),
-                ("out_x3", i32)]
+                ("drop_p", f32), ("drop_site", C.c_uint32), ("drop_seed", C.c_uint64), ("out_x3", i32)]
 
 
 class QformerEmbedArgs(C.Structure):
@@ -65,7 +65,7 @@ class AttentionBwdArgs(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("Tq", i32), ("Tk", i32), ("head_dim", i32),
                 ("q", vp), ("k", vp), ("v", vp), ("dout", vp), ("ldq", i64), ("ldk", i64), ("ldv", i64), ("lddo", i64),
                 ("key_mask", vp), ("scale", f32), ("dq", vp), ("dk", vp), ("dv", vp), ("lddq", i64), ("lddk", i64), ("lddv", i64),
-                ("scratch", vp), ("scratch_bytes", sz)]
+                ("scratch", vp), ("scratch_bytes", sz), ("drop_p", f32), ("drop_site", C.c_uint32), ("drop_seed", C.c_uint64)]
 
 
 class ProfEntry(C.Structure):
@@ -155,6 +155,7 @@ SIGNATURES = {
     "sprc_layernorm_bwd_workspace_bytes": (sz, [i32, i32]),
     "sprc_layernorm_bwd": (i32, [vp, i64, vp, vp, i64, f32, i32, i32, vp, i64, vp, vp, vp, sz, vp]),
     "sprc_attention_bwd": (i32, [C.POINTER(AttentionBwdArgs), vp]),
+    "sprc_dropout_f32": (i32, [vp, vp, vp, sz, C.c_uint64, C.c_uint32, f32, vp]),
     "sprc_qformer_embed_rows": (i32, [C.POINTER(QformerEmbedArgs), vp, vp]),
     "sprc_qformer_embed_bwd": (i32, [C.POINTER(QformerEmbedArgs), vp, vp, i64, vp, vp, vp]),
     "sprc_sim_max_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]),

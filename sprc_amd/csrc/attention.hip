@@ -56,6 +56,7 @@ struct AttnParams {
     const char* v2; int64_t ldv2;
     const int32_t* idx1; const int32_t* idx2;
     int x3;                         // > 0 (fp16, resident kernel): `out` rows in the SPRC_F16X3 layout, x3 = logical row width H * dh
+    uint32_t drop_thresh, drop_site; uint64_t drop_seed; float drop_scale;    // fp32 kernel, training: probability dropout (thresh 0: none)
 };
 
 // byte address of head h of key/value token t of batch b (t in the concatenated key axis)
@@ -894,8 +895,9 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnParams p) {
         const int key = lane + i * 64;
         if (key < p.Tk) {
             const float e = expf(s[i] - mx);
-            ps[key] = e;
-            sum += e;
+            sum += e;                                   // the softmax is normalised BEFORE the dropout (Qformer.py:260-264)
+            ps[key] = (p.drop_thresh == 0 || drop_keep(p.drop_seed, p.drop_site, (((uint64_t)b * p.H + h) * p.Tq + qi) * p.Tk + key, p.drop_thresh))
+                          ? e * p.drop_scale : 0.f;
         }
     }
     sum = wave_sum(sum);
@@ -1038,7 +1040,10 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
     AttnParams p{a->B, a->H, a->Tq, Tk_all, a->head_dim, (const char*)a->q, a->ldq, (const char*)a->k, a->ldk,
                  (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale,
                  a->Tk, (const char*)a->k2, a->ldk2, (const char*)a->v2, a->ldv2, a->kv_index, a->kv2_index,
-                 a->out_x3 ? a->H * a->head_dim : 0};
+                 a->out_x3 ? a->H * a->head_dim : 0,
+                 a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u, a->drop_site, a->drop_seed, a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f};
+    SPRC_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f && (a->drop_p == 0.f || (a->dtype == SPRC_F32 && !two)),
+                 "sprc_attention: drop_p in [0, 1); probability dropout is a mode of the fp32 (training) kernel, one key segment");
     SPRC_REQUIRE(!a->out_x3 || (a->dtype == SPRC_F16 && a->Tq <= 128 && a->ldo >= 2 * (int64_t)a->H * a->head_dim && (a->H * a->head_dim) % 4 == 0),
                  "sprc_attention: out_x3 needs dtype SPRC_F16, Tq <= 128 (resident kernel), ldo >= 2 H head_dim (a split row is 4 bytes per column)");
     hipStream_t st = (hipStream_t)s;

@@ -127,6 +127,16 @@ __host__ __device__ __forceinline__ int64_t map_row(const sprc_rowmap& m, int64_
     return (r / m.rows_per_group) * (int64_t)m.group_stride + (r % m.rows_per_group) + m.group_offset;
 }
 
+// counter-based dropout mask (sprc.h: sprc_dropout_f32): element `idx` of site `site` is KEPT iff the high word of the hash >= thresh
+__host__ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t site, uint64_t idx, uint32_t thresh) {
+    uint64_t z = seed + (uint64_t)site * 0x9E3779B97F4A7C15ull + idx * 0xD1B54A32D192ED03ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32) >= thresh;
+}
+static inline uint32_t drop_thresh(float p) { return (uint32_t)((double)p * 4294967296.0); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -149,6 +149,7 @@ struct AttnBwdParams {
     const float* key_mask; float scale;
     float *dq, *dk, *dv; int64_t lddq, lddk, lddv;
     float *P, *dS;
+    uint32_t drop_thresh, drop_site; uint64_t drop_seed; float drop_scale;
 };
 constexpr int AB_MAXK = 9;                      // keys per lane -> Tk <= 576
 // one wave per (b, h, query row): P row, dS row, dQ row
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdParams p) {
     sq[wave][lane] = p.q[((int64_t)b * p.Tq + i) * p.ldq + h * 64 + lane];
     sdo[wave][lane] = p.dout[((int64_t)b * p.Tq + i) * p.lddo + h * 64 + lane];
     __syncthreads();
-    float s[AB_MAXK], dp[AB_MAXK];
+    float s[AB_MAXK], dp[AB_MAXK], dmask[AB_MAXK];
     float mx = -INFINITY;
 #pragma unroll
     for (int c = 0; c < AB_MAXK; ++c) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdParams p) {
                 d = fmaf(sdo[wave][e], vv.x, d); d = fmaf(sdo[wave][e + 1], vv.y, d); d = fmaf(sdo[wave][e + 2], vv.z, d); d = fmaf(sdo[wave][e + 3], vv.w, d);
             }
             s[c] = a * p.scale + (p.key_mask ? p.key_mask[(int64_t)b * p.Tk + key] : 0.f);
-            dp[c] = d;
+            dp[c] = d;                                   // dL/d(dropped probability)
             mx = fmaxf(mx, s[c]);
         }
     }
@@ -193,7 +194,14 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdParams p) {
     float dot = 0.f;
 #pragma unroll
     for (int c = 0; c < AB_MAXK; ++c)
-        if (lane + c * 64 < p.Tk) { s[c] *= inv; dot += s[c] * dp[c]; }
+        if (lane + c * 64 < p.Tk) {
+            s[c] *= inv;
+            // out = (D o P) V: dL/dP = D o (dO V^T); the softmax backward below runs on the UNdropped P
+            const float dm = (p.drop_thresh == 0 || drop_keep(p.drop_seed, p.drop_site, (uint64_t)rr * p.Tk + (lane + c * 64), p.drop_thresh)) ? p.drop_scale : 0.f;
+            dp[c] *= dm;
+            dot += s[c] * dp[c];
+            dmask[c] = dm;
+        }
     dot = wave_sum(dot);
     float* Prow = p.P + rr * p.Tk;
     float* dSrow = p.dS + rr * p.Tk;
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(AttnBwdParams p) {
         if (key < p.Tk) {
             const float ds = s[c] * (dp[c] - dot);
             sds[wave][key] = ds;
-            if (live) { Prow[key] = s[c]; dSrow[key] = ds; }
+            if (live) { Prow[key] = s[c] * dmask[c]; dSrow[key] = ds; }     // the keys kernel needs D o P (dV = (D o P)^T dO)
         }
     }
     __syncthreads();
@@ -437,6 +445,26 @@ extern "C" int sprc_layernorm_bwd(const float* x, int64_t ldx, const float* gamm
     return SPRC_OK;
 }
 
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, const float* resid, float* y, size_t n, uint64_t seed, uint32_t site,
+                                                      uint32_t thresh, float scale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = drop_keep(seed, site, i, thresh) ? x[i] * scale : 0.f;
+        if (resid != nullptr) v += resid[i];
+        y[i] = v;
+    }
+}
+
+extern "C" int sprc_dropout_f32(const float* x, const float* resid, float* y, size_t n, uint64_t seed, uint32_t site, float p, sprc_stream s) {
+    SPRC_REQUIRE(x && y, "sprc_dropout_f32: null pointer");
+    SPRC_REQUIRE(p >= 0.f && p < 1.f, "sprc_dropout_f32: p = %f outside [0, 1)", (double)p);
+    if (n == 0) return SPRC_OK;
+    const size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)s, x, resid, y, n, seed, site,
+                       p > 0.f ? drop_thresh(p) : 0u, p > 0.f ? 1.0f / (1.0f - p) : 1.0f);
+    SPRC_CHECK_LAUNCH("sprc_dropout_f32");
+    return SPRC_OK;
+}
+
 extern "C" int sprc_attention_bwd(const sprc_attention_bwd_args* a, sprc_stream s) {
     SPRC_REQUIRE(a && a->q && a->k && a->v && a->dout && a->dq && a->dk && a->dv && a->scratch, "sprc_attention_bwd: null pointer");
     SPRC_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0 && a->head_dim == 64, "sprc_attention_bwd: head_dim must be 64 (the Q-Former's)");
@@ -446,7 +474,9 @@ extern "C" int sprc_attention_bwd(const sprc_attention_bwd_args* a, sprc_stream 
     SPRC_REQUIRE(a->scratch_bytes >= need, "sprc_attention_bwd: scratch too small (%zu needed)", need);
     float* P = (float*)a->scratch;
     AttnBwdParams p{a->B, a->H, a->Tq, a->Tk, a->q, a->k, a->v, a->dout, a->ldq, a->ldk, a->ldv, a->lddo, a->key_mask, a->scale,
-                    a->dq, a->dk, a->dv, a->lddq, a->lddk, a->lddv, P, P + (size_t)a->B * a->H * a->Tq * a->Tk};
+                    a->dq, a->dk, a->dv, a->lddq, a->lddk, a->lddv, P, P + (size_t)a->B * a->H * a->Tq * a->Tk,
+                    a->drop_p > 0.f ? drop_thresh(a->drop_p) : 0u, a->drop_site, a->drop_seed, a->drop_p > 0.f ? 1.0f / (1.0f - a->drop_p) : 1.0f};
+    SPRC_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f, "sprc_attention_bwd: drop_p in [0, 1)");
     const int64_t rows = (int64_t)a->B * a->H * a->Tq, keys = (int64_t)a->B * a->H * a->Tk;
     hipLaunchKernelGGL(attn_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, p);
     SPRC_CHECK_LAUNCH("sprc_attention_bwd(rows)");

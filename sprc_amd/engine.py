@@ -156,9 +156,9 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype: int, want32=T
 
 
 def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=None, out=None,
-              k2=None, v2=None, Tk2=0, ld2=0, kv_index=None, kv2_index=None):
+              k2=None, v2=None, Tk2=0, ld2=0, kv_index=None, kv2_index=None, drop=None):
     """k2 / v2 (optional): a second key segment of Tk2 tokens appended to the key axis; kv_index / kv2_index: int32 [B] batch
-    rows of the two segments (see sprc_attention_args)."""
+    rows of the two segments (see sprc_attention_args).  drop = (p, seed, site): training-mode dropout on the probabilities (fp32)."""
     lib = L.load()
     dt = _SPRC_DT[q.dtype]
     if out is None:
@@ -171,6 +171,8 @@ def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=No
     if k2 is not None:
         a.k2, a.ldk2, a.v2, a.ldv2, a.Tk2 = k2.data_ptr(), ld2, v2.data_ptr(), ld2, Tk2
     a.kv_index, a.kv2_index = _ptr(kv_index), _ptr(kv2_index)
+    if drop is not None:
+        a.drop_p, a.drop_seed, a.drop_site = drop
     L.check(lib.sprc_attention(C.byref(a), _stream()), "sprc_attention")
     return out
 

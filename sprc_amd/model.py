@@ -12,8 +12,10 @@ All compute goes through libsprc_hip.so (sprc_amd/engine.py); there is no torch/
 calling these methods on a CPU-resident model raises.
 
 Deliberate differences from the reference (documented in DESIGN.md):
-  * eval semantics always (dropout = identity).  The reference's CIRR scripts leave the Q-Former in
-    train mode, which makes their features stochastic.
+  * `extract_target_features` / `inference` / `inference_rerank` have eval semantics always (dropout = identity).  The reference's
+    CIRR scripts leave the Q-Former in train mode, which makes their features stochastic.  The TRAINING
+    forward honours `model.train()` as the reference does (blip_fine_tune_2.py:290): Q-Former dropout p = 0.1 at the reference's
+    four sites, reproducible counter-based masks (`dropout_seed`).
   * `inference` always returns a 2-D [B,N] tensor (the reference's `.squeeze()` collapses B=1 / N=1).
   * `forward` (the three training losses, align_prompt.py:95-200) carries autograd history: its backward runs the HIP backward
     kernels (sprc_amd/train.py, csrc/train.hip), so the reference's training loop runs against this class.
@@ -67,7 +69,10 @@ class Blip2QformerCirAlignPrompt(nn.Module):
         self.register_parameter("temp", nn.Parameter(0.07 * torch.ones([], device=device), requires_grad=True))
         self._engine: Optional[E.Engine] = None
         self._tokenizer = tokenizer
-        self.training = False
+        # training mode is nn.Module's default, as for the reference class (lavis load_model_and_preprocess(is_eval=False) leaves it on)
+        self.dropout_p = 0.1                       # hidden_dropout_prob = attention_probs_dropout_prob of bert-base-uncased (blip2.py:48)
+        self.dropout_seed = 0                      # masks of step n: counter-based, seeded by (dropout_seed, n) -- set it for reproducible runs
+        self._drop_step = 0
 
     # ---- construction helpers (lavis/models/base_model.py:58-80) --------------------------------
     @classmethod
@@ -110,9 +115,8 @@ class Blip2QformerCirAlignPrompt(nn.Module):
         self._drop_engines()
         return super()._apply(fn, *a, **k)
 
-    def train(self, mode: bool = True):
-        self.training = False                                     # inference engine: eval semantics only
-        return self
+    # `train()` / `eval()` are nn.Module's: the flag decides whether the differentiable `forward` runs the Q-Former's dropout
+    # (blip_fine_tune_2.py:290 trains in train mode, :322 validates in eval mode); the inference methods ignore it.
 
     @property
     def tokenizer(self):
@@ -240,7 +244,11 @@ class _TrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, image, target, input_ids, attention_mask, names, *params):
         P = {n: p_.detach() for n, p_ in model.named_parameters()}
-        step = TrainStep(model.cfg, {n: t.float().contiguous() for n, t in P.items()}, model._train_engine())
+        # train mode: the Q-Former's dropout (Qformer.py:113,264,293,379; p from the BERT config: 0.1), a fresh mask every step
+        drop_p = model.dropout_p if model.training else 0.0
+        model._drop_step += 1
+        seed = (int(model.dropout_seed) * 0x9E3779B1 + model._drop_step) & 0xFFFFFFFFFFFFFFFF
+        step = TrainStep(model.cfg, {n: t.float().contiguous() for n, t in P.items()}, model._train_engine(), dropout_p=drop_p, seed=seed)
         losses = step.forward(image.to(model.device), target.to(model.device), input_ids, attention_mask)
         ctx.step, ctx.names = step, names
         return losses["loss_itc"].clone(), losses["loss_rtc"].clone(), losses["loss_align"].clone()

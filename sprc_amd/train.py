@@ -8,7 +8,9 @@ prompt_tokens and temp.  This module sequences the library's fp32 kernels -- spr
 sprc_layernorm and the backward kernels of csrc/train.hip -- into that graph; torch provides device memory and copies (slicing,
 concatenation) only.  Every gradient ACCUMULATION happens inside a kernel: products accumulate through the GEMM's residual
 epilogue (dW += dY^T X is `sprc_gemm(A = dY^T, W = X^T, resid = dW)`), the embedding scatters and the loss kernels add in place.
-Eval semantics as everywhere in this engine: dropout = identity (the reference trains with p = 0.1).
+Dropout (the reference trains with the Q-Former in train mode, blip_fine_tune_2.py:290: p = 0.1 at Qformer.py:113,264,293,379) is
+`TrainStep(dropout_p=...)`: counter-based masks (sprc_dropout_f32 / sprc_attention.drop_*) regenerated in backward, never stored;
+dropout_p = 0 is the eval-mode graph.  The frozen ViT is always in eval mode (align_prompt.py:67-68).
 
     step = TrainStep(cfg, params, engine)            # params: {state-dict name: fp32 CUDA tensor}
     losses = step.forward(image, target, input_ids, attention_mask)
@@ -90,10 +92,20 @@ class _K:
                                             ws.numel(), _st()), "sprc_layernorm_bwd")
         return dx
 
-    def attention(self, q, k, v, B, H, Tq, Tk, mask, scale):
-        return E.attention(q, k, v, B, H, Tq, Tk, 64, q.stride(0), k.stride(0), v.stride(0), scale, key_mask=mask)
+    def attention(self, q, k, v, B, H, Tq, Tk, mask, scale, drop=None):
+        return E.attention(q, k, v, B, H, Tq, Tk, 64, q.stride(0), k.stride(0), v.stride(0), scale, key_mask=mask, drop=drop)
 
-    def attention_bwd(self, q, k, v, dout, B, H, Tq, Tk, mask, scale):
+    def dropout(self, x, drop, resid=None):
+        """x * keep / (1 - p) (+ resid); drop = (p, seed, site) or None = identity (then x + resid when resid is given)"""
+        if drop is None:
+            return x if resid is None else x + resid
+        y = torch.empty_like(x)
+        p, seed, site = drop
+        L.check(self.lib.sprc_dropout_f32(x.data_ptr(), None if resid is None else resid.data_ptr(), y.data_ptr(), x.numel(), seed, site, p, _st()),
+                "sprc_dropout_f32")
+        return y
+
+    def attention_bwd(self, q, k, v, dout, B, H, Tq, Tk, mask, scale, drop=None):
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         scratch = self.ws("attn", 2 * B * H * Tq * Tk * 4)
         a = L.AttentionBwdArgs()
@@ -103,6 +115,8 @@ class _K:
         a.key_mask, a.scale = (None if mask is None else mask.data_ptr()), scale
         a.dq, a.dk, a.dv, a.lddq, a.lddk, a.lddv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0)
         a.scratch, a.scratch_bytes = scratch.data_ptr(), scratch.numel()
+        if drop is not None:
+            a.drop_p, a.drop_seed, a.drop_site = drop
         L.check(self.lib.sprc_attention_bwd(C.byref(a), _st()), "sprc_attention_bwd")
         return dq, dk, dv
 
@@ -132,13 +146,20 @@ class _Linear:
         return k.gemm(dy, Wt, resid=acc, out=acc)
 
 
+# dropout sites (the numbering of oracle/sprc_oracle.py: drop_site): pass * 256 + layer * 8 + kind, embeddings pass * 256 + 255
+DROP_SELF_P, DROP_SELF_OUT, DROP_CROSS_P, DROP_CROSS_OUT, DROP_FFN_Q, DROP_FFN_T, DROP_EMB = 0, 1, 2, 3, 4, 5, 255
+
+
 class TrainStep:
-    def __init__(self, cfg, params: Dict[str, torch.Tensor], engine: E.Engine):
+    def __init__(self, cfg, params: Dict[str, torch.Tensor], engine: E.Engine, dropout_p: float = 0.0, seed: int = 0):
         # `engine` runs the FROZEN ViT trunk only (vit_forward + its pre-ln_vision stream): fp32, or fp16 as under the reference's autocast
         # (blip_fine_tune_2.py:293); everything that trains -- ln_vision, the Q-Former, the heads -- is computed here on the exact-fp32 GEMM
         if engine.dt not in (L.SPRC_F32, L.SPRC_F16) or engine.fp8:
             raise L.SprcError("the training step's frozen trunk runs on an fp32 or fp16 engine")
         self.cfg, self.P, self.eng = cfg, params, engine
+        if not 0.0 <= dropout_p < 1.0:
+            raise ValueError("dropout_p must be in [0, 1)")
+        self.drop_p, self.seed = float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF
         self.dev = engine.device
         self.k = _K(self.dev)
         q = cfg.qformer
@@ -152,6 +173,12 @@ class TrainStep:
         return not (name.startswith("visual_encoder.") or name.startswith("itm_head.") or name.startswith("Qformer.cls.")
                     or name.endswith("position_ids"))
 
+    def _drop(self, pass_id: int, layer: int, kind: int):
+        """(p, seed, site) of one dropout call, or None in eval mode"""
+        if self.drop_p <= 0.0:
+            return None
+        return (self.drop_p, self.seed, pass_id * 256 + (DROP_EMB if kind == DROP_EMB else layer * 8 + kind))
+
     # ---- building blocks with saved context -------------------------------------------------------------------------
     def _lin(self, w, b=None):
         key = w
@@ -159,27 +186,27 @@ class TrainStep:
             self._lins[key] = _Linear(self.k, self.P, self.G, w, b)
         return self._lins[key]
 
-    def _attn_fwd(self, pre, xq, xkv, B, Sq, Sk, mask):
-        """BertSelfAttention + BertSelfOutput (Qformer.py:175-295): LN(dense(softmax(q k^T / 8 + mask) v) + xq).  xq [B*Sq, Hd],
-        xkv [B*Sk, Dk]."""
+    def _attn_fwd(self, pre, xq, xkv, B, Sq, Sk, mask, dp=None, do=None):
+        """BertSelfAttention + BertSelfOutput (Qformer.py:175-295): LN(dropout(dense(dropout(softmax(q k^T / 8 + mask)) v)) + xq).
+        xq [B*Sq, Hd], xkv [B*Sk, Dk]; dp / do: the dropout calls on the probabilities (:264) and on the dense output (:293)."""
         k = self.k
         lq, lk, lv = self._lin(pre + "self.query.weight", pre + "self.query.bias"), self._lin(pre + "self.key.weight", pre + "self.key.bias"), \
             self._lin(pre + "self.value.weight", pre + "self.value.bias")
         lo = self._lin(pre + "output.dense.weight", pre + "output.dense.bias")
         q, kk, v = lq.fwd(xq), lk.fwd(xkv), lv.fwd(xkv)
-        ctx = k.attention(q, kk, v, B, self.H, Sq, Sk, mask, self.sc)
-        t = lo.fwd(ctx, resid=xq)
+        ctx = k.attention(q, kk, v, B, self.H, Sq, Sk, mask, self.sc, drop=dp)
+        t = lo.fwd(ctx, resid=xq) if do is None else k.dropout(lo.fwd(ctx), do, resid=xq)
         gn, bn = pre + "output.LayerNorm.weight", pre + "output.LayerNorm.bias"
         y = k.ln(t, self.P[gn], self.P[bn], self.eps)
-        return y, dict(pre=pre, xq=xq, xkv=xkv, q=q, k=kk, v=v, ctx=ctx, t=t, B=B, Sq=Sq, Sk=Sk, mask=mask, same=xkv is xq)
+        return y, dict(pre=pre, xq=xq, xkv=xkv, q=q, k=kk, v=v, ctx=ctx, t=t, B=B, Sq=Sq, Sk=Sk, mask=mask, same=xkv is xq, dp=dp, do=do)
 
     def _attn_bwd(self, c, dy, dkv_acc=None):
         """-> dxq; the key / value source gets its gradient added into dkv_acc (cross-attention) or into dxq (self-attention)."""
         k, pre = self.k, c["pre"]
         gn, bn = pre + "output.LayerNorm.weight", pre + "output.LayerNorm.bias"
         dt = k.ln_bwd(c["t"], self.P[gn], dy, self.eps, self.G[gn], self.G[bn])
-        dctx = self._lin(pre + "output.dense.weight").bwd(c["ctx"], dt)
-        dq, dk, dv = k.attention_bwd(c["q"], c["k"], c["v"], dctx, c["B"], self.H, c["Sq"], c["Sk"], c["mask"], self.sc)
+        dctx = self._lin(pre + "output.dense.weight").bwd(c["ctx"], dt if c["do"] is None else k.dropout(dt, c["do"]))
+        dq, dk, dv = k.attention_bwd(c["q"], c["k"], c["v"], dctx, c["B"], self.H, c["Sq"], c["Sk"], c["mask"], self.sc, drop=c["dp"])
         dxq = self._lin(pre + "self.query.weight").bwd(c["xq"], dq, acc=dt)          # residual path + query path
         tgt = dxq if c["same"] else dkv_acc
         need = tgt is not None
@@ -187,20 +214,21 @@ class TrainStep:
         r = self._lin(pre + "self.value.weight").bwd(c["xkv"], dv, acc=r if need else None, need_dx=need)
         return r if c["same"] else dxq
 
-    def _ffn_fwd(self, pre_i, pre_o, x):
-        """LN(W2 gelu(W1 x) + x)  (Qformer.py:482-490)"""
+    def _ffn_fwd(self, pre_i, pre_o, x, do=None):
+        """LN(dropout(W2 gelu(W1 x)) + x)  (Qformer.py:482-490, dropout :379)"""
         k = self.k
         z = self._lin(pre_i + "dense.weight", pre_i + "dense.bias").fwd(x)
         h = k.gelu(z)
-        t = self._lin(pre_o + "dense.weight", pre_o + "dense.bias").fwd(h, resid=x)
+        lo = self._lin(pre_o + "dense.weight", pre_o + "dense.bias")
+        t = lo.fwd(h, resid=x) if do is None else k.dropout(lo.fwd(h), do, resid=x)
         y = k.ln(t, self.P[pre_o + "LayerNorm.weight"], self.P[pre_o + "LayerNorm.bias"], self.eps)
-        return y, dict(pre_i=pre_i, pre_o=pre_o, x=x, z=z, h=h, t=t)
+        return y, dict(pre_i=pre_i, pre_o=pre_o, x=x, z=z, h=h, t=t, do=do)
 
     def _ffn_bwd(self, c, dy):
         k = self.k
         gn, bn = c["pre_o"] + "LayerNorm.weight", c["pre_o"] + "LayerNorm.bias"
         dt = k.ln_bwd(c["t"], self.P[gn], dy, self.eps, self.G[gn], self.G[bn])
-        dh = self._lin(c["pre_o"] + "dense.weight").bwd(c["h"], dt)
+        dh = self._lin(c["pre_o"] + "dense.weight").bwd(c["h"], dt if c["do"] is None else k.dropout(dt, c["do"]))
         dz = k.gelu_bwd(c["z"], dh)
         return self._lin(c["pre_i"] + "dense.weight").bwd(c["x"], dz, acc=dt)
 
@@ -208,27 +236,28 @@ class TrainStep:
         """[B, S, Hd] -> contiguous [B * (hi - lo), Hd] (a copy: data movement only)"""
         return x3[:, lo:hi, :].reshape(-1, x3.shape[-1]).contiguous()
 
-    def _stack_fwd(self, x, B, S, mask, enc, Tenc):
-        """12 BertLayers (Qformer.py:408-480) over x [B*S, Hd]; enc [B*Tenc, Dv] or None."""
+    def _stack_fwd(self, x, B, S, mask, enc, Tenc, pass_id=0):
+        """12 BertLayers (Qformer.py:408-480) over x [B*S, Hd]; enc [B*Tenc, Dv] or None; pass_id numbers the dropout sites."""
         Hd, Lq = self.Hd, self.Lq
         ctxs: List[dict] = []
+        D = lambda l, kind: self._drop(pass_id, l, kind)                      # noqa: E731
         for l in range(self.cfg.qformer.layers):
             b = f"Qformer.bert.encoder.layer.{l}."
-            a, ca = self._attn_fwd(b + "attention.", x, x, B, S, S, mask)
+            a, ca = self._attn_fwd(b + "attention.", x, x, B, S, S, mask, D(l, DROP_SELF_P), D(l, DROP_SELF_OUT))
             c = dict(self_attn=ca, S=S)
             if enc is not None:
                 a3 = a.view(B, S, Hd)
                 qa = self._rows(a3, 0, Lq) if S > Lq else a
                 if l % self.cfg.qformer.cross_freq == 0:
-                    qa, c["cross"] = self._attn_fwd(b + "crossattention.", qa, enc, B, Lq, Tenc, None)
-                oq, c["ffn_q"] = self._ffn_fwd(b + "intermediate_query.", b + "output_query.", qa)
+                    qa, c["cross"] = self._attn_fwd(b + "crossattention.", qa, enc, B, Lq, Tenc, None, D(l, DROP_CROSS_P), D(l, DROP_CROSS_OUT))
+                oq, c["ffn_q"] = self._ffn_fwd(b + "intermediate_query.", b + "output_query.", qa, D(l, DROP_FFN_Q))
                 if S > Lq:
-                    ot, c["ffn_t"] = self._ffn_fwd(b + "intermediate.", b + "output.", self._rows(a3, Lq, S))
+                    ot, c["ffn_t"] = self._ffn_fwd(b + "intermediate.", b + "output.", self._rows(a3, Lq, S), D(l, DROP_FFN_T))
                     x = torch.cat([oq.view(B, Lq, Hd), ot.view(B, S - Lq, Hd)], dim=1).reshape(B * S, Hd)
                 else:
                     x = oq
             else:
-                x, c["ffn_t"] = self._ffn_fwd(b + "intermediate.", b + "output.", a)
+                x, c["ffn_t"] = self._ffn_fwd(b + "intermediate.", b + "output.", a, D(l, DROP_FFN_T))
             ctxs.append(c)
         return x, ctxs
 
@@ -262,17 +291,22 @@ class TrainStep:
         a.no_img = int(no_img)
         return a
 
-    def _embed_fwd(self, B, Lq, Lt, query, q_bstride, ids, no_img=False):
-        """BertEmbeddings.forward (Qformer.py:78-114): rows -> LayerNorm.  query: [.., Lq, Hd] fp32 (q_bstride 0 = shared)."""
+    def _embed_fwd(self, B, Lq, Lt, query, q_bstride, ids, no_img=False, pass_id=0):
+        """BertEmbeddings.forward (Qformer.py:78-114): rows -> LayerNorm -> dropout (:113).  query: [.., Lq, Hd] fp32 (q_bstride 0 = shared)."""
         p = "Qformer.bert.embeddings."
         a = self._embed_args(B, Lq, Lt, query, q_bstride, ids, no_img)
         pre = self.k.empty(B * (Lq + Lt), self.Hd)
         L.check(self.k.lib.sprc_qformer_embed_rows(C.byref(a), pre.data_ptr(), _st()), "sprc_qformer_embed_rows")
         y = self.k.ln(pre, self.P[p + "LayerNorm.weight"], self.P[p + "LayerNorm.bias"], self.eps)
-        return y, dict(args=a, pre=pre, keep=(query, ids))
+        do = self._drop(pass_id, 0, DROP_EMB)
+        if do is not None:
+            y = self.k.dropout(y, do)
+        return y, dict(args=a, pre=pre, keep=(query, ids), do=do)
 
     def _embed_bwd(self, c, dy, dquery, dq_bstride):
         p = "Qformer.bert.embeddings."
+        if c["do"] is not None:
+            dy = self.k.dropout(dy, c["do"])
         dpre = self.k.ln_bwd(c["pre"], self.P[p + "LayerNorm.weight"], dy, self.eps, self.G[p + "LayerNorm.weight"], self.G[p + "LayerNorm.bias"])
         L.check(self.k.lib.sprc_qformer_embed_bwd(C.byref(c["args"]), dpre.data_ptr(), None if dquery is None else dquery.data_ptr(), dq_bstride,
                                                   self.G[p + "word_embeddings.weight"].data_ptr(), self.G[p + "position_embeddings.weight"].data_ptr(),
@@ -315,19 +349,19 @@ class TrainStep:
         L.check(k.lib.sprc_qformer_mask(am.data_ptr(), mask.data_ptr(), B, Lq, Lt, _st()), "sprc_qformer_mask")
         qt = P["query_tokens"].view(Lq, Hd)
         # P1: fusion pass 1 (:120-127)      P2: pass 2 on its query rows (:129-134)
-        x1, self.e1 = self._embed_fwd(B, Lq, Lt, qt, 0, ids)
-        h1, self.c1 = self._stack_fwd(x1, B, S, mask, raw_ref, T)
-        x2, self.e2 = self._embed_fwd(B, Lq, Lt, h1, S * Hd, ids)
-        h2, self.c2 = self._stack_fwd(x2, B, S, mask, None, 0)
+        x1, self.e1 = self._embed_fwd(B, Lq, Lt, qt, 0, ids, pass_id=0)
+        h1, self.c1 = self._stack_fwd(x1, B, S, mask, raw_ref, T, pass_id=0)
+        x2, self.e2 = self._embed_fwd(B, Lq, Lt, h1, S * Hd, ids, pass_id=1)
+        h2, self.c2 = self._stack_fwd(x2, B, S, mask, None, 0, pass_id=1)
         fusion, self.hf = self._head_fwd("text_proj", h2.view(B, S, Hd)[:, Lq, :].contiguous())
         # P3: target image pass (:141-155)
-        x3, self.e3 = self._embed_fwd(B, Lq, 0, qt, 0, None)
-        h3, self.c3 = self._stack_fwd(x3, B, Lq, None, raw_tgt, T)
+        x3, self.e3 = self._embed_fwd(B, Lq, 0, qt, 0, None, pass_id=2)
+        h3, self.c3 = self._stack_fwd(x3, B, Lq, None, raw_tgt, T, pass_id=2)
         tfeat, self.ht = self._head_fwd("vision_proj", h3)
         # P4: text-only prompt pass (:170-179)
         pt = P["prompt_tokens"].view(Lq, Hd)
-        x4, self.e4 = self._embed_fwd(B, Lq, Lt, pt, 0, ids, no_img=True)
-        h4, self.c4 = self._stack_fwd(x4, B, S, mask, None, 0)
+        x4, self.e4 = self._embed_fwd(B, Lq, Lt, pt, 0, ids, no_img=True, pass_id=3)
+        h4, self.c4 = self._stack_fwd(x4, B, S, mask, None, 0, pass_id=3)
         tonly, self.ho = self._head_fwd("text_proj", h4.view(B, S, Hd)[:, 0, :].contiguous())
         # losses (:157-167, :181-193)
         temp = float(P["temp"])

@@ -204,6 +204,30 @@ def test_training_gradients_match_reference(golden_dir):
     print(f"\n[oracle training gradients] worst functional error / ||g|| = {worst:.2e} over {len(grads)} tensors")
 
 
+def test_training_gradients_with_dropout_match_reference(golden_dir):
+    """The reference AS IT TRAINS (blip_fine_tune_2.py:290: `.train()`, Q-Former dropout p = 0.1 at Qformer.py:113,264,293,379; ViT in
+    eval) with the masks injected by oracle/gen_golden.py: the oracle regenerates the same counter-based masks (drop_keep) and must
+    reproduce the three losses and all 337 gradients; and the masks matter -- the eval-mode losses are different numbers."""
+    g = np.load(golden_dir / "train_dropout_eva.npz", allow_pickle=False)
+    g0 = np.load(golden_dir / "train_eva.npz", allow_pickle=False)
+    assert float(g["dropout_p"]) == 0.1 and int(g["dropout_sites"]) == 61 + 37 + 49 + 37      # per pass: embeddings + 2 x 12 self-attention (+ 2 x 6 cross) + the FFN outputs
+    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    B = int(g["batch"])
+    images = synth.make_images(2 * B, seed=int(g["seed"]))
+    ids, mask = torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"])
+    losses, grads = O.training_gradients(sd, cfg, images[:B], images[B:], ids, mask, drop=(int(g["drop_seed_effective"]), float(g["dropout_p"])))
+    for k in ("loss_itc", "loss_rtc", "loss_align"):
+        assert abs(float(losses[k]) - float(g[k])) < 1e-5
+    assert abs(float(g["loss_itc"]) - float(g0["loss_itc"])) > 1e-3          # dropout changes the numbers
+    worst = check_gradients_against_golden(g, grads, 1e-4)
+    print(f"\n[oracle training gradients, dropout on] worst functional error / ||g|| = {worst:.2e} over {len(grads)} tensors")
+    # the mask itself: keep rate, determinism, independence of sites
+    k1 = O.drop_keep(123, O.drop_site(0, 3, O.DROP_FFN_Q), 200000, 0.1)
+    k2 = O.drop_keep(123, O.drop_site(0, 3, O.DROP_FFN_T), 200000, 0.1)
+    assert abs(k1.mean() - 0.9) < 3e-3 and abs((k1 & k2).mean() - 0.81) < 4e-3 and np.array_equal(k1, O.drop_keep(123, O.drop_site(0, 3, O.DROP_FFN_Q), 200000, 0.1))
+
+
 def test_rerank_matches_reference(golden_dir):
     """N2: the oracle's inference_rerank against the reference's Blip2QformerCirRerank.inference_rerank (514-token
     cross-attention + itm_head + softmax), batched (3 queries x 4 candidates) and the single-query branch."""

@@ -82,14 +82,22 @@ def test_loss_kernels():
 
 
 # ---- backward (N4) -------------------------------------------------------------------------------------------------------
-def _train_case(golden_dir):
-    g = np.load(golden_dir / "train_eva.npz", allow_pickle=False)
+def _train_case(golden_dir, name="train_eva.npz"):
+    """model in EVAL mode for the eval-mode golden; the dropout golden's model is in train mode with the golden's dropout seed"""
+    g = np.load(golden_dir / name, allow_pickle=False)
     cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
     sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
     B = int(g["batch"])
     model = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=8)
     assert not model.load_state_dict(sd, strict=False).missing_keys
     model = model.to(DEV)
+    assert model.training                        # nn.Module's default, as for the reference class
+    if "dropout_p" in g.files and float(g["dropout_p"]) > 0:
+        model.train()
+        model.dropout_seed = int(g["dropout_seed"])
+        assert model.dropout_p == float(g["dropout_p"])
+    else:
+        model.eval()
     model.tokenizer = _Tok(torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]))
     images = synth.make_images(2 * B, seed=int(g["seed"]))
     return g, cfg, sd, model, {"image": images[:B].to(DEV), "target": images[B:].to(DEV), "text_input": ["caption"] * B}
@@ -122,6 +130,58 @@ def test_backward_matches_the_reference_gradients(golden_dir):
     assert worst < 3e-4
 
 
+def test_backward_with_dropout_matches_the_reference_in_train_mode(golden_dir):
+    """the reference TRAINS with `blip_model.train()` (blip_fine_tune_2.py:290): Q-Former dropout p = 0.1 on the
+    embeddings, the attention probabilities and the two output.dense branches (Qformer.py:113,264,293,379).  `model.train()` now does
+    that here: counter-based masks (sprc_dropout_f32 / sprc_attention.drop_*) regenerated in backward.  Golden: the unmodified reference
+    in train mode with the SAME masks injected (oracle/gen_golden.py: inject_dropout_masks) -- losses and all 337 gradients."""
+    import json
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_oracle_golden import check_gradients_against_golden
+    g, cfg, sd, model, batch = _train_case(golden_dir, "train_dropout_eva.npz")
+    w = json.loads(str(g["grad_weights"]))
+    losses = model(batch)
+    for k in losses:
+        assert float(losses[k].detach()) == pytest.approx(float(g[k]), abs=5e-5), k
+    sum(w[k] * v for k, v in losses.items()).backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    worst = check_gradients_against_golden(g, grads, 3e-4)
+    print(f"\n[train backward fp32, dropout p = 0.1] losses {[round(float(v), 5) for v in losses.values()]}; worst functional error / ||g|| = {worst:.2e} over {len(grads)} tensors")
+    # a second step draws NEW masks (the step counter enters the seed); eval mode switches them off and gives the eval-mode golden's numbers
+    l2 = model(batch)
+    assert abs(float(l2["loss_itc"].detach()) - float(g["loss_itc"])) > 1e-4
+    g0 = np.load(golden_dir / "train_eva.npz", allow_pickle=False)
+    model.eval()
+    l3 = model(batch)
+    assert float(l3["loss_itc"].detach()) == pytest.approx(float(g0["loss_itc"]), abs=5e-5)
+    # under torch.no_grad() (validation inside the training script, blip_fine_tune_2.py:322-330) there is no dropout either way
+    model.train()
+    with torch.no_grad():
+        l4 = model(batch)
+    assert float(l4["loss_itc"]) == pytest.approx(float(g0["loss_itc"]), abs=2e-4)
+
+
+def test_dropout_kernel_matches_the_cpu_mask():
+    """sprc_dropout_f32 == the oracle's drop_keep (the integer hash both sides compute), with and without the fused residual add"""
+    lib = L.load()
+    n, seed, site, p = 100003, 0x1234567890ABCDEF, 777, 0.1
+    x, r = torch.randn(n), torch.randn(n)
+    xd, rd, y = x.to(DEV), r.to(DEV), torch.empty(n, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    keep = torch.from_numpy(O.drop_keep(seed, site, n, p))
+    L.check(lib.sprc_dropout_f32(xd.data_ptr(), None, y.data_ptr(), n, seed, site, p, st))
+    assert torch.equal(y.cpu(), torch.where(keep, x * (1.0 / (1.0 - p)), torch.zeros(())).float()) or \
+        torch.allclose(y.cpu(), x * keep.float() * (1.0 / (1.0 - p)), rtol=1e-6, atol=0)
+    assert torch.equal(y.cpu() != 0, keep & (x != 0))
+    L.check(lib.sprc_dropout_f32(xd.data_ptr(), rd.data_ptr(), y.data_ptr(), n, seed, site, p, st))
+    torch.testing.assert_close(y.cpu(), x * keep.float() * (1.0 / (1.0 - p)) + r, rtol=1e-6, atol=1e-6)
+    L.check(lib.sprc_dropout_f32(xd.data_ptr(), None, y.data_ptr(), n, seed, site, 0.0, st))
+    assert torch.equal(y.cpu(), x)
+
+
 def test_fp16_frozen_trunk_in_the_training_step(golden_dir):
     """train_vit_dtype="fp16": the frozen ViT of a training step on the fp16 engine, as the reference's loop runs it under autocast
     (blip_fine_tune_2.py:293); ln_vision, the Q-Former and the heads stay on the fp32 path.  Losses within 1e-3 of the fp32-trunk step
@@ -139,7 +199,7 @@ def test_fp16_frozen_trunk_in_the_training_step(golden_dir):
     l32, g32 = grads_of(model)
     m16 = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=8, train_vit_dtype="fp16")
     assert not m16.load_state_dict(sd, strict=False).missing_keys
-    m16 = m16.to(DEV)
+    m16 = m16.to(DEV).eval()
     m16.tokenizer = model.tokenizer
     l16, g16 = grads_of(m16)
     assert m16._train_engine().dt == L.SPRC_F16 and model._train_engine().dt == L.SPRC_F32
