@@ -40,6 +40,15 @@ class _K:
         self.lib = L.load()
         self.dev = device
         self._ws: Dict[str, torch.Tensor] = {}
+        self._xt: Dict[int, tuple] = {}          # transposes of SAVED activations, per step: id(x) -> (x, x^T); holding x keeps its address its own
+
+    def transpose_saved(self, x):
+        """x^T of an activation the forward pass saved: the q / k / v linears of an attention (and both FFN halves of a row set) read the
+        same input, so its transpose is formed once per step.  Gradients (dy) are transient tensors and are not cached."""
+        hit = self._xt.get(id(x))
+        if hit is None or hit[0] is not x:
+            hit = self._xt[id(x)] = (x, self.transpose(x))
+        return hit[1]
 
     def empty(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.dev)
@@ -135,7 +144,8 @@ class _Linear:
     def bwd(self, x, dy, acc=None, need_dx=True):
         """dW += dy^T x, db += colsum(dy); returns dx (+ acc: the running gradient of x from other paths) or None."""
         k = self.k
-        k.gemm(k.transpose(dy), k.transpose(x), resid=self.gW, out=self.gW)
+        assert self.W.shape[0] % 32 == 0 or not need_dx, "dX = dY . W reduces over the N output features: the fp32 GEMM needs N % 32 == 0"
+        k.gemm(k.transpose(dy), k.transpose_saved(x), resid=self.gW, out=self.gW)
         if self.gb is not None:
             k.colsum(dy, self.gb)
         if not need_dx:
@@ -335,6 +345,7 @@ class TrainStep:
         S = Lq + Lt
         self.G = {n: torch.zeros_like(P[n]) for n in self.trainable}
         self._lins: Dict[str, _Linear] = {}
+        self.k._xt.clear()
         ids = input_ids.to(device=self.dev, dtype=torch.int64).contiguous()
         am = attention_mask.to(device=self.dev, dtype=torch.int64).contiguous()
         # frozen ViT (align_prompt.py:64-69) + ln_vision; its INPUT is kept: ln_vision trains
@@ -418,4 +429,5 @@ class TrainStep:
         gv, bv = self.P["ln_vision.weight"], G["ln_vision.bias"]
         for pre, d in ((self.pre_ref, denc_ref), (self.pre_tgt, denc_tgt)):
             k.ln_bwd(pre, gv, d, self.cfg.ln_vision_eps, G["ln_vision.weight"], bv, need_dx=False)
+        k._xt.clear()
         return G
