@@ -110,16 +110,18 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias=None, resid=None, out_dtype=None
 
 
 def gemm_pair(A: torch.Tensor, W0: torch.Tensor, W1: torch.Tensor, bias0, bias1, amap0, amap1, cmap0, cmap1, M: int,
-              out: torch.Tensor, resid=None, out_dtype=None, act=L.ACT_NONE) -> torch.Tensor:
+              out: torch.Tensor, resid=None, out_dtype=None, act=L.ACT_NONE, K=None, k8=0) -> torch.Tensor:
     """Two products of identical shape in one launch (sprc_gemm_pair): rows amap0 of A through W0 into rows cmap0 of `out`,
-    rows amap1 through W1 into rows cmap1."""
+    rows amap1 through W1 into rows cmap1.  K / k8: a split-precision pair (operands = fp16 views of split rows, see `gemm`)."""
     lib = L.load()
     dt = _SPRC_DT[A.dtype]
-    N, K = W0.shape
+    N = W0.shape[0]
+    K = W0.shape[1] if K is None else K
     odt = dt if out_dtype is None else out_dtype
     gs = []
     for W, bias, amap, cmap in ((W0, bias0, amap0, cmap0), (W1, bias1, amap1, cmap1)):
         g = L.GemmArgs()
+        g.k8 = k8
         g.M, g.N, g.K, g.dtype, g.out_dtype, g.act, g.max32 = M, N, K, dt, odt, act, 0
         g.A, g.lda, g.amap = A.data_ptr(), A.stride(0), amap
         g.W, g.ldw = W.data_ptr(), W.stride(0)
