@@ -127,7 +127,10 @@ def test_two_rccl_ranks_one_per_gpu_equal_the_single_process_harness():
 
 
 def _c4_worker(rank, world, port, out, depth):
+    import time
+    t0 = time.time()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)                     # eight ranks on the box's 16 cores: the CPU-side image draws must not oversubscribe them
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sprc_amd import dist_eval as DE
@@ -137,7 +140,7 @@ def _c4_worker(rank, world, port, out, depth):
     top, sub = DE.generate_cirr_test_dicts_sharded(DC.C4Test(gallery.names, case["ref"], case["groups"]), gallery, model, DC.TXT,
                                                    num_workers=0, gallery_batch_size=64)
     torch.cuda.synchronize()
-    out[rank] = dict(top=top, sub=sub)
+    out[rank] = dict(top=top, sub=sub, seconds=time.time() - t0)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -159,11 +162,14 @@ def test_c4_sizes_eight_ranks_sharing_the_gpu_equal_the_single_process_submissio
     owner-routed fusion with unequal per-rank query counts, both exchanges, the 8 x 51-candidate merge.  The two submission dicts (top-50
     names, subset top-3) of every rank must equal the single-process harness's, entry for entry."""
     from sprc_amd import harness as H
+    import time
     world, depth = 8, 1
+    t0 = time.time()
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_c4_worker, args=(world, _free_port(), out, depth), nprocs=world, join=True)
         res = {r: dict(out[r]) for r in range(world)}
+    t1 = time.time()
     case = DC.build_c4(0)
     model = _c4_model(case, depth)
     gallery = DC.LazyGallery(DC.C4_IMAGES, seed=7)
@@ -171,6 +177,8 @@ def test_c4_sizes_eight_ranks_sharing_the_gpu_equal_the_single_process_submissio
     assert len(names) == DC.C4_IMAGES
     want_top, want_sub = H.generate_cirr_test_dicts(DC.C4Test(gallery.names, case["ref"], case["groups"]), model, (feats, raw), names, DC.TXT)
     assert len(want_top) == DC.C4_QUERIES and all(len(v) == 50 for v in want_top.values()) and all(len(v) == 3 for v in want_sub.values())
+    print(f"\n[C4 sizes] 8 ranks sharing the GPU: {t1 - t0:.0f} s wall (rank bodies {min(res[r]['seconds'] for r in res):.0f} .. "
+          f"{max(res[r]['seconds'] for r in res):.0f} s); single process: {time.time() - t1:.0f} s")
     for r in range(world):
         assert res[r]["top"] == want_top and res[r]["sub"] == want_sub, f"rank {r}"
 
