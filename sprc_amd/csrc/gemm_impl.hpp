@@ -388,7 +388,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                                 if constexpr (sizeof(T) <= 2) v[e] = gelu_fast(v[e]);
                                 else v[e] = gelu_erf(v[e]);
                             }
-                            if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = quick_gelu(v[e]);
+                            if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = sizeof(T) <= 2 ? quick_gelu_fast(v[e]) : quick_gelu(v[e]);
                             if constexpr (RES) v[e] += rv[mi & 1][it][e];
                             if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= p.out_scale;
                         }
@@ -441,7 +441,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                             if constexpr (sizeof(T) <= 2) v = gelu_fast(v);
                             else v = gelu_erf(v);
                         }
-                        if constexpr (ACT == SPRC_ACT_QUICKGELU) v = quick_gelu(v);
+                        if constexpr (ACT == SPRC_ACT_QUICKGELU) v = sizeof(T) <= 2 ? quick_gelu_fast(v) : quick_gelu(v);
                         if (rrow != nullptr) v += rrow[col];
                         if constexpr (std::is_same<OutT, fp8_t>::value) v *= p.out_scale;
                         store_out1<OutT>(crow + col, v, p.N, col);
