@@ -244,9 +244,18 @@ def main():
     # `--gpus 2` as a plumbing check) the ranks share devices and the two tiny all_gathers are staged through gloo:
     # RCCL refuses two ranks on one device.  The line then says so in config.backend -- it is not a scaling number.
     backend = "nccl" if world <= ndev else "gloo"
-    if world > 1:
+    # SPRC_BENCH_FORCE_DIST=1: a ONE-rank process group anyway (with SPRC_DIST_ALWAYS_EXCHANGE=1 both all_gathers run): the code an
+    # N-GPU launch executes -- RCCL init with device_id, the device check, the exchanges, the per-rank record -- on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("SPRC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "WORLD_SIZE" not in os.environ:                   # forced one-rank group outside a launcher
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT=str(sk.getsockname()[1]))
+            sk.close()
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -354,7 +363,7 @@ def main():
         return ranker.rank(fusion, TOPK)                                          # R6 similarity + R7 top-k (+ exchanges)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -385,7 +394,7 @@ def main():
     L.check(lib.sprc_prof_collect(prof), "sprc_prof_collect")
     lib.sprc_prof_enable(0)
     per_rank_ms = [round(dt / a.steps * 1e3, 3)]
-    if world > 1:
+    if use_dist:
         # value uses the MAX over ranks (the contract); every rank's own step time rides along so that a straggler shows in the record
         times = [None] * world
         torch.distributed.all_gather_object(times, dt)
@@ -439,9 +448,9 @@ def main():
                                    f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
                        "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_streams": a.qf_streams, "pipeline": int(bool(a.pipeline)),
-                       "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if world > 1 and backend == "nccl" else None),
+                       "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if use_dist and backend == "nccl" else None),
                        "per_rank_ms_per_step": per_rank_ms,
-                       "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if world > 1 else None},
+                       "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if use_dist else None},
             "roofline": {"bound": "mfma", "kernel": GEMM_KERNELS[a.dtype], "achieved": round(ach, 1), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                          "step_frac": round(step_tflop / (dt / a.steps) / peak, 4), "step_alg_tflop": round(step_tflop, 2),
@@ -479,7 +488,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_images)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _run(*args):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(*args, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -37,3 +37,13 @@ def test_live_bench_line():
     # a dtype the reference does not benchmark with is refused by argparse, not silently accepted
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dtype", "int8"], cwd=ROOT, capture_output=True, text=True)
     assert p.returncode != 0
+
+
+def test_bench_line_through_a_one_rank_rccl_group():
+    """The code `bench.py --gpus N` runs on an N-GPU node -- `init_process_group("nccl", device_id=...)`, the one-rank-per-device check, both
+    device-side all_gathers of the sharded ranking, the per-rank step-time record, barrier + destroy -- executed on the 1-GPU box through a
+    ONE-rank RCCL group (SPRC_BENCH_FORCE_DIST=1, SPRC_DIST_ALWAYS_EXCHANGE=1).  N > 1 itself stays unmeasured until a multi-GPU box runs it."""
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", SPRC_BENCH_FORCE_DIST="1", SPRC_DIST_ALWAYS_EXCHANGE="1")
+    c = d["config"]
+    assert c["rccl_ranks"] == 1 and c["backend"] == "rccl" and c["per_rank_ms_per_step"] == [d["ms_per_step"]]
+    assert d["n_gpus"] == 1 and 500 < d["value"] < 5000
