@@ -507,6 +507,10 @@ def main():
     # a larger draw (256 gallery images x 128 queries = 32768 scores, seed 2): the tail of the 16-bit engines' error distribution
     if a.full and want("planted_big"):
         planted_goldens(GOLD / "planted_big_eva.npz", n_img=256, n_q=128, vit_depth=None, seed=2)
+    # a second 256 x 128 ViT-g draw (round 4, seed 3): the tail of the error distributions behind the "engine vs the reference's GPU
+    # arithmetic" statement (tests/test_fp16_gpu.py) rests on more than one large draw
+    if a.full and want("planted_big_s3"):
+        planted_goldens(GOLD / "planted_big_eva_s3.npz", n_img=256, n_q=128, vit_depth=None, seed=3)
     if a.full and want("planted_clip_s1"):
         planted_goldens(GOLD / "planted_full_clip_s1.npz", n_img=96, n_q=48, vit_depth=None, model_type="pretrain_vitL", seed=1)
     # the same cases on a checkpoint whose trunk Conv / Linear tensors hold fp16 VALUES -- what a GPU-trained reference checkpoint
