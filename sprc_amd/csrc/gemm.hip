@@ -75,14 +75,14 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     p.k8 = a->k8;
     hipStream_t st = (hipStream_t)s;
-    const double osz = a->max32 ? 4.0 / 32.0 : a->out_dtype == SPRC_F16X3 ? 4.0 : (double)dtype_size(a->out_dtype);     // a split row: 4 bytes per column
+    const double osz = a->max32 ? 4.0 / 32.0 : a->out_dtype == SPRC_F16X3 ? 6.0 : (double)dtype_size(a->out_dtype);
     const double np = b != nullptr ? 2.0 : 1.0;
     // algorithmic work: the product the caller MEANS (k_alg: a split-precision launch reduces over K = 3 k_alg, the patch embedding
     // over zero padding); executed flops are recorded next to it
     SPRC_REQUIRE(a->k_alg >= 0 && a->k_alg <= a->K, "sprc_gemm: k_alg=%d outside [0, K=%d]", a->k_alg, a->K);
     const double ka = a->k_alg > 0 ? (double)a->k_alg : (double)a->K;
     ProfScope prof(a->dtype == SPRC_F32 ? SPRC_K_GEMM_F32 : SPRC_K_GEMM_BF16, st, np * 2.0 * a->M * (double)a->N * ka,
-                   np * (((double)a->M * ka + (double)a->N * ka) * (a->k8 > 0 ? 4.0 : (double)es) + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))),
+                   np * (((double)a->M * ka + (double)a->N * ka) * es + (double)a->M * a->N * (osz + (a->resid ? 4.0 : 0.0))),
                    np * 2.0 * a->M * (double)a->N * ((double)a->K + a->k8));     // executed MACs: fp16 ones + e4m3 correction ones (half the time each)
     if (a->k8 > 0) return gemm_dispatch_f16e(a, p, st);
     if (a->dtype == SPRC_FP8) return gemm_dispatch_fp8(a, p, st);

@@ -12,8 +12,6 @@
 //   gemm_kernel       128 x 128, 4 waves (2 x 2), wave tile 64 x 64, 2 WGs / CU (small grids, remainder rows, split-K,
 //                     and every fp32 GEMM; also instantiated as a lock-step 256 x 256 for the fp32 engine)
 //     bf16: v_mfma_f32_32x32x16_bf16, K-tile = 64 elements;  f32: v_mfma_f32_32x32x2_f32 (exact fp32), 32 elements
-//   MIX instantiations of both (fp16 operands, gemm_f16e.hip): split-precision products -- fp16 K-tiles, then e4m3 K-tiles on the
-//     MX-scaled MFMA into the same accumulators (sprc.h: SPRC_F16X3, sprc_gemm_args.k8)
 // The dispatcher (launch<>) chooses between them -- and a "256x256 on the first M & ~255 rows + 128x128 on the rest"
 // split -- with a round-count cost model.
 // Data movement: K-tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds through an SRSRC based at the tile's
