@@ -121,8 +121,8 @@ typedef struct {
      * out_dtype == SPRC_FP8: the result is multiplied by out_scale (= 1 / the consumer's a_scale) and saturated to +-448. */
     const float* w_scale; float a_scale; float out_scale;
     /* ABI 4: the LOGICAL reduction length this product stands for, for the profiler's algorithmic flop count only (0 = K).
-     * A split-precision product over [hi | lo | hi] . [W_hi | W_hi | W_lo] launches K = 3 k_alg; the patch embedding launches its
-     * zero-padded K (640 for 588).  Never changes what is computed. */
+     * The patch embedding launches its zero-padded K (640 for 588); a split-precision product (k8 below) counts its fp16 K as the
+     * algorithmic one and its e4m3 correction elements as executed work only.  Never changes what is computed. */
     int32_t k_alg;
     /* ABI 4, dtype SPRC_F16 only: split-precision product.  Every row of A and W holds K fp16 elements FOLLOWED by k8 e4m3fn elements
      * (k8 == 2K: the SPRC_F16X3 layout above; lda / ldw in fp16 units >= K + k8 / 2); out = epilogue(sum over the fp16 part +

@@ -12,7 +12,7 @@ from pathlib import Path
 # SPRC_LIB_PATH: an A/B build of the same library (tools/build_variant.sh); never a different implementation
 LIB_PATH = Path(os.environ.get("SPRC_LIB_PATH") or (Path(__file__).resolve().parent / "libsprc_hip.so"))
 
-SPRC_F16X3 = 4                                        # storage layout of split-precision fp16 activations ([hi | lo | hi], sprc.h)
+SPRC_F16X3 = 4                                        # storage layout of split-precision activations: rows [hi fp16 | lo e4m3 | hi e4m3] (sprc.h)
 SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: IEEE half (compute dtype since ABI 3); FP8: OCP e4m3fn operands
 ABI_VERSION = 4
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
