@@ -332,6 +332,16 @@ int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_embeds, int3
                       const int64_t* input_ids, const int64_t* attention_mask, int32_t B,
                       float* fusion, void* fusion16, void* ws, size_t ws_bytes, sprc_stream s);
 
+/* sprc_qformer_fuse with the K|V projections of the reference images GIVEN: kv = rows of an sprc_qformer_encode_kv output
+ * ([n, enc_tokens, n_cross*2*hidden], compute dtype), query b reads row kv_index[b] (device int32 [B]; NULL = b).  A gallery
+ * image that serves as the reference of several queries (CIRR: the reference image of a query is a gallery image,
+ * validate_blip.py:377,395-399) is then projected once instead of once per query -- 6.7 of a query's 29.3 GFLOP
+ * (Qformer.py:191-193 inside align_prompt.py:332-339).  Same bits as sprc_qformer_fuse on the same images.  16-bit models.
+ * OPTIONAL: bench.py does not use it (BASELINE.md's per-query figure counts the projection). */
+int sprc_qformer_fuse_kv(const sprc_qformer_model* m, const void* kv, int32_t enc_tokens, const int32_t* kv_index,
+                         const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
+                         void* fusion16, void* ws, size_t ws_bytes, sprc_stream s);
+
 /* ------------------------------------------------------------------------------------------
  * Stage-2 rerank: Blip2QformerCirRerank.inference_rerank,
  * lavis/models/blip2_models/blip2_qformer_cir_rerank.py:399-445; caller cirr_test_submission.py:88-112.

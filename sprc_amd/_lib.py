@@ -138,6 +138,7 @@ SIGNATURES = {
     "sprc_vit_forward": (i32, [C.POINTER(VitModel), vp, i32, vp, vp, sz, vp]),
     "sprc_qformer_image": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, vp, sz, vp]),
     "sprc_qformer_fuse": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, i32, vp, vp, vp, sz, vp]),
+    "sprc_qformer_fuse_kv": (i32, [C.POINTER(QformerModel), vp, i32, vp, vp, vp, i32, vp, vp, vp, sz, vp]),
     "sprc_qformer_kv_workspace_bytes": (sz, [C.POINTER(QformerModel), i32, i32]),
     "sprc_qformer_encode_kv": (i32, [C.POINTER(QformerModel), vp, i32, i32, vp, vp, sz, vp]),
     "sprc_qformer_itm_workspace_bytes": (sz, [C.POINTER(QformerModel), i32]),

@@ -122,7 +122,7 @@ def _warn_index_cache_ignored(index_cache):
 
 
 def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="fp16", index_cache=None, gpu_preprocess=False,
-                       vit_depth=None):
+                       vit_depth=None, reuse_reference_kv=False):
     from .data_utils import CIRRDataset
     model, txt = _load(blip_model_name, backbone, blip_model_path, dtype, vit_depth)
     preprocess, workers = _preprocess(gpu_preprocess, model.device)
@@ -134,7 +134,7 @@ def blip_validate_cirr(blip_model_name, backbone, blip_model_path, dtype="fp16",
         r = compute_cirr_val_metrics_sharded(relative_val, classic_val, model, txt, num_workers=workers)
     else:
         feats, names = _gallery(classic_val, model, index_cache, "cirr-val", backbone, dtype, workers)
-        r = compute_cirr_val_metrics(relative_val, model, feats, names, txt)
+        r = compute_cirr_val_metrics(relative_val, model, feats, names, txt, reuse_reference_kv=reuse_reference_kv and dtype != "fp32")
     g1, g2, g3, r1, r5, r10, r50 = r
     out = {"group_recall_at1": g1, "group_recall_at2": g2, "group_recall_at3": g3, "recall_at1": r1, "recall_at5": r5,
            "recall_at10": r10, "recall_at50": r50, "mean(R@5+R_s@1)": (g1 + r5) / 2, "arithmetic_mean": mean(r),
@@ -187,12 +187,15 @@ def main(argv=None):
                    help="fp16 (default): the reference's GPU numerics -- fp16 ViT, Q-Former at ~fp32 product precision")
     p.add_argument("--index-cache", default=None, help="directory of gallery feature stores (sprc_amd/index.py): encode once, reuse")
     p.add_argument("--gpu-preprocess", action="store_true", help="pad / bicubic resize / crop / normalise on the GPU (bit-identical to the PIL transform)")
+    p.add_argument("--reuse-reference-kv", action="store_true", help="CIRR: project each distinct reference image to the Q-Former's cross-attention "
+                   "K|V once instead of once per query (same scores; single-process, 16-bit engines)")
     p.add_argument("--vit-depth", type=int, default=None, help="truncate the ViT to N blocks (entry-point smoke tests only)")
     a = p.parse_args(argv)
     if a.dataset.lower() not in ("fashioniq", "cirr"):
         raise ValueError("Dataset should be either 'CIRR' or 'FashionIQ")
     if a.dataset.lower() == "cirr":
-        return blip_validate_cirr(a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache, a.gpu_preprocess, a.vit_depth)
+        return blip_validate_cirr(a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache, a.gpu_preprocess, a.vit_depth,
+                                  reuse_reference_kv=a.reuse_reference_kv)
     return blip_validate_fiq(["dress", "toptee", "shirt"], a.blip_model_name, a.backbone, a.model_path, a.dtype, a.index_cache,
                              a.gpu_preprocess, a.vit_depth)
 

@@ -990,7 +990,7 @@ static int attention16(const sprc_attention_args* a, const AttnParams& p, bool t
     static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
     // SPRC_ATTN_DMA: 0 = the first streaming form (register staging), 2 / 3 = the DMA form with a ring of that many tiles
     static const int dma = [] { const char* e = getenv("SPRC_ATTN_DMA"); return e ? atoi(e) : 2; }();
-    if (stream && dma && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
+    if (stream && dma && !small && a->key_mask == nullptr && !two && a->kv_index == nullptr && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
         static const int nw4 = [] { const char* e = getenv("SPRC_ATTN_NW"); return e ? atoi(e) == 4 : 0; }();
         if (dma == 2 && nw4) {
             if (a->head_dim <= 64) return launch_dma<64, false, 4, F16, 2>(p, st);
@@ -1005,7 +1005,7 @@ static int attention16(const sprc_attention_args* a, const AttnParams& p, bool t
         if (a->head_dim == 88) return launch_dma<96, true, 3, F16, 3>(p, st);
         return launch_dma<96, false, 3, F16, 3>(p, st);
     }
-    if (stream && !small && a->key_mask == nullptr && !two && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
+    if (stream && !small && a->key_mask == nullptr && !two && a->kv_index == nullptr && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
         if (a->head_dim <= 64) return launch_stream<64, false, 3, F16>(p, st);
         if (a->head_dim == 88) return launch_stream<96, true, 3, F16>(p, st);     // denominator from the ones row of the padded V^T tile
         return launch_stream<96, false, 3, F16>(p, st);
@@ -1035,7 +1035,9 @@ extern "C" int sprc_attention(const sprc_attention_args* a, sprc_stream s) {
     SPRC_REQUIRE(a->B > 0 && a->H > 0 && a->Tq > 0 && a->Tk > 0 && a->head_dim > 0, "sprc_attention: bad shape");
     const bool two = a->k2 != nullptr;
     SPRC_REQUIRE(!two || (a->v2 && a->Tk2 > 0 && !a->key_mask), "sprc_attention: a second key segment needs k2, v2, Tk2 > 0 and no key mask");
-    SPRC_REQUIRE(two || (!a->kv_index && !a->kv2_index && !a->v2), "sprc_attention: kv_index / kv2_index / v2 come with a second key segment (k2)");
+    SPRC_REQUIRE(two || (!a->kv2_index && !a->v2), "sprc_attention: kv2_index / v2 come with a second key segment (k2)");
+    SPRC_REQUIRE(!a->kv_index || two || a->Tq <= 128 || a->dtype == SPRC_F32,
+                 "sprc_attention: kv_index on a single key segment is served by the resident kernels (Tq <= 128) and the fp32 one");
     const int Tk_all = a->Tk + (two ? a->Tk2 : 0);
     AttnParams p{a->B, a->H, a->Tq, Tk_all, a->head_dim, (const char*)a->q, a->ldq, (const char*)a->k, a->ldk,
                  (const char*)a->v, a->ldv, (char*)a->out, a->ldo, a->key_mask, a->scale,

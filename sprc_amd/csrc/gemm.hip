@@ -75,7 +75,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     p.k8 = a->k8;
     hipStream_t st = (hipStream_t)s;
-    const double osz = a->max32 ? 4.0 / 32.0 : a->out_dtype == SPRC_F16X3 ? 6.0 : (double)dtype_size(a->out_dtype);
+    const double osz = a->max32 ? 4.0 / 32.0 : a->out_dtype == SPRC_F16X3 ? 4.0 : (double)dtype_size(a->out_dtype);     // a split row: 4 bytes per column
     const double np = b != nullptr ? 2.0 : 1.0;
     // algorithmic work: the product the caller MEANS (k_alg: a split-precision launch reduces over K = 3 k_alg, the patch embedding
     // over zero padding); executed flops are recorded next to it

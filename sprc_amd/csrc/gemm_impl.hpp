@@ -12,6 +12,8 @@
 //   gemm_kernel       128 x 128, 4 waves (2 x 2), wave tile 64 x 64, 2 WGs / CU (small grids, remainder rows, split-K,
 //                     and every fp32 GEMM; also instantiated as a lock-step 256 x 256 for the fp32 engine)
 //     bf16: v_mfma_f32_32x32x16_bf16, K-tile = 64 elements;  f32: v_mfma_f32_32x32x2_f32 (exact fp32), 32 elements
+//   MIX instantiations of both (fp16 operands, gemm_f16e.hip): split-precision products -- fp16 K-tiles, then e4m3 K-tiles on the
+//     MX-scaled MFMA into the same accumulators (sprc.h: SPRC_F16X3, sprc_gemm_args.k8)
 // The dispatcher (launch<>) chooses between them -- and a "256x256 on the first M & ~255 rows + 128x128 on the rest"
 // split -- with a round-count cost model.
 // Data movement: K-tiles go HBM/L2 -> LDS directly (buffer_load_dwordx4 ... lds through an SRSRC based at the tile's
@@ -82,7 +84,7 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 struct fp8_t { uint8_t bits; };        // OCP e4m3fn (gfx950), operand / output tag type
-struct f16x3_t { uint16_t bits; };     // OUTPUT tag: the split-precision layout SPRC_F16X3 ([hi | lo | hi], see sprc.h)
+struct f16x3_t { uint16_t bits; };     // OUTPUT tag: split-precision rows SPRC_F16X3 ([hi fp16 | lo e4m3 | hi e4m3], see sprc.h)
 
 // saturating fp32 -> 2 x e4m3fn (v_cvt_pk_fp8_f32: RNE; inputs clamped to +-448 first, the format has no infinity)
 __device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, bool hi) {

@@ -183,7 +183,7 @@ static size_t qf_plan(const sprc_qformer_model* m, int B, int enc_tokens, Bump& 
 }
 
 // which activation buffers of a call with layer-kind mask `cm` are kept in the split layout: a buffer is split when one of the
-// layers that read it reduces over three segments
+// layers that read it runs the split product (fp16 + e4m3 segments)
 struct X3Layouts { bool ln, ctx, ffn; };
 static X3Layouts x3_layouts(int cm) {
     return X3Layouts{(cm & (SPRC_X3_QKV | SPRC_X3_CROSS_Q | SPRC_X3_FFN_IN | SPRC_X3_HEADS)) != 0,
@@ -193,9 +193,9 @@ static X3Layouts x3_layouts(int cm) {
 // one Q-Former encoder stack over x32/x16 [B, S, hidden]; cross-attention + query FFN on rows [:Lq] when
 // `kv` is given (Qformer.py:434-468), text FFN on rows [Lq:]; text FFN on all rows otherwise (:469-475).
 // Split-precision (fp16 engine): `cm` is the CALL's mask over layer kinds (SPRC_X3_*, a subset of the packed mask m->x3).
-// A layer whose kind is in cm reduces over all three segments of its input -- kept in the SPRC_F16X3 layout [hi | lo | hi], leading
-// dimension 3 x width -- against its [W_hi | W_hi | W_lo] weights (K' = 3 K on the SAME fp16 GEMM kernels: products to ~2^-21); the
-// others reduce over the hi segment only (a packed weight matrix is then read through its leading dimension 3 K).  The three groups
+// A layer whose kind is in cm runs the split product (sprc_gemm k8 = 2 K) on its input -- kept as SPRC_F16X3 rows [hi fp16 | lo e4m3 |
+// hi e4m3], 4 x width bytes -- against split weight rows [W_hi | W 2^6 | W_lo 2^18] (fp16 K-tiles, then e4m3 K-tiles on the MX-scaled
+// MFMA: products to ~2^-16); the others reduce over the hi segment only (packed weight rows are then read through their pitch).  The three groups
 // of activation buffers (LayerNorm copies, attention outputs, FFN hidden) are split only when one of their consumers is in cm
 // (x3_layouts).  q / k / v and the attention probabilities stay plain fp16.
 static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int B, int S, const KvSrc* kvs,
@@ -524,11 +524,14 @@ extern "C" int sprc_qformer_image(const sprc_qformer_model* m, const float* raw,
     return sprc_l2norm_rows(q.proj, m->embed_dim, feats, feats16, m->embed_dim, B * Lq, m->embed_dim, dt, st);
 }
 
+// kv != nullptr: the K|V projections of the reference images are GIVEN (rows of an sprc_qformer_encode_kv output, query b reads row
+// kv_index[b], or b when kv_index is null) and ref_embeds is not read
 static int qformer_fuse_impl(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,
                              const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
-                             void* fusion16, const float* prompt_tokens, float* loss_align, void* ws, size_t ws_bytes, sprc_stream s) {
+                             void* fusion16, const float* prompt_tokens, float* loss_align, void* ws, size_t ws_bytes, sprc_stream s,
+                             const void* kv = nullptr, const int32_t* kv_index = nullptr) {
     RUN(check_qf(m));
-    SPRC_REQUIRE(ref_embeds && input_ids && attention_mask && fusion && ws && B > 0, "sprc_qformer_fuse: bad arguments");
+    SPRC_REQUIRE((ref_embeds || kv) && input_ids && attention_mask && fusion && ws && B > 0, "sprc_qformer_fuse: bad arguments");
     SPRC_REQUIRE(enc_tokens == 257, "sprc_qformer_fuse: enc_tokens=%d (sprc_qformer_workspace_bytes plans for 257)", enc_tokens);
     SPRC_REQUIRE(((uintptr_t)ws % 256) == 0, "sprc_qformer_fuse: workspace must be 256-byte aligned");
     Bump b(ws, ws_bytes);
@@ -541,8 +544,8 @@ static int qformer_fuse_impl(const sprc_qformer_model* m, const float* ref_embed
     hipStream_t st = (hipStream_t)s;
     const int dt = m->dtype, Hd = m->hidden, Lq = m->num_query, Lt = m->max_txt, S = Lq + Lt;
     const int cm = m->x3_fuse;
-    RUN(qf_encode_kv(m, st, q.enc, q.kv, ref_embeds, B, enc_tokens, cm));
-    const KvSrc kvs{q.kv, enc_tokens, nullptr, nullptr, 0, nullptr, (int64_t)m->n_cross * 2 * Hd};
+    if (kv == nullptr) RUN(qf_encode_kv(m, st, q.enc, q.kv, ref_embeds, B, enc_tokens, cm));
+    const KvSrc kvs{kv != nullptr ? kv : q.kv, enc_tokens, kv != nullptr ? kv_index : nullptr, nullptr, 0, nullptr, (int64_t)m->n_cross * 2 * Hd};
     RUN(sprc_qformer_mask(attention_mask, q.mask, B, Lq, Lt, st));
     sprc_qformer_embed_args e;
     memset(&e, 0, sizeof(e));
@@ -565,6 +568,14 @@ static int qformer_fuse_impl(const sprc_qformer_model* m, const float* ref_embed
     const sprc_rowmap cls_row = {1, S, Lq};
     RUN(head(m, st, cm, B, q.g16, m->text_proj, q.proj, cls_row));
     return sprc_l2norm_rows(q.proj, m->embed_dim, fusion, fusion16, m->embed_dim, B, m->embed_dim, dt, st);
+}
+
+extern "C" int sprc_qformer_fuse_kv(const sprc_qformer_model* m, const void* kv, int32_t enc_tokens, const int32_t* kv_index,
+                                    const int64_t* input_ids, const int64_t* attention_mask, int32_t B, float* fusion,
+                                    void* fusion16, void* ws, size_t ws_bytes, sprc_stream s) {
+    SPRC_REQUIRE(kv != nullptr && ((uintptr_t)kv % 16) == 0, "sprc_qformer_fuse_kv: kv must be a 16-byte aligned sprc_qformer_encode_kv output");
+    SPRC_REQUIRE(m && is16(m->dtype), "sprc_qformer_fuse_kv: a 16-bit model (the fp32 engine recomputes its projections)");
+    return qformer_fuse_impl(m, nullptr, enc_tokens, input_ids, attention_mask, B, fusion, fusion16, nullptr, nullptr, ws, ws_bytes, s, kv, kv_index);
 }
 
 extern "C" int sprc_qformer_fuse(const sprc_qformer_model* m, const float* ref_embeds, int32_t enc_tokens,

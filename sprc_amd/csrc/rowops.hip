@@ -348,7 +348,7 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
                reinterpret_cast<const _Float16*>(a->add16), a->ld_add, a->sum32, a->ld_sum};
     const dim3 grid((a->M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
     ProfScope prof(SPRC_K_ROWOPS, (hipStream_t)s, 8.0 * a->M * (double)a->D,
-                   (double)a->M * a->D * (4.0 + (a->y32 ? 4.0 : 0.0) + (a->y16 ? (double)dtype_size(a->out_dtype) : 0.0) +
+                   (double)a->M * a->D * (4.0 + (a->y32 ? 4.0 : 0.0) + (a->y16 ? (a->out_dtype == SPRC_F16X3 ? 4.0 : (double)dtype_size(a->out_dtype)) : 0.0) +
                                           (a->add16 ? 2.0 : 0.0) + (a->sum32 ? 4.0 : 0.0)));
     if (a->out_dtype == SPRC_FP8) {
         SPRC_REQUIRE(a->y16 != nullptr && a->y16_scale > 0.f && a->add16 == nullptr && ((uintptr_t)a->y16 % 4) == 0,

@@ -532,6 +532,31 @@ class Engine:
         return fusion, f16
 
     @_on_device
+    def qformer_fuse_kv(self, kv: torch.Tensor, kv_index: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        """`qformer_fuse` with the reference images' cross-attention K|V projections GIVEN: kv = `encode_kv` rows [n, 257, kv_width]
+        (compute dtype), query b reads row kv_index[b].  An image that is the reference of several queries is projected once (6.7 of a
+        query's 29.3 GFLOP); same bits as `qformer_fuse` on the same images.  Optional: bench.py does not use it."""
+        if not self.is16 or kv.dtype != self.tdt or kv.dim() != 3 or kv.shape[1:] != (self.cfg.vit.tokens, self.kv_width) or not kv.is_contiguous():
+            raise ValueError("kv must be a contiguous Engine.encode_kv output [n, tokens, kv_width] of a 16-bit engine")
+        idx = kv_index.to(device=self.device, dtype=torch.int32).contiguous()
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        mask = attention_mask.to(device=self.device, dtype=torch.int64).contiguous()
+        B, E = idx.shape[0], self.cfg.embed_dim
+        if ids.shape != (B, self.cfg.max_txt_len) or mask.shape != ids.shape:
+            raise ValueError(f"input_ids/attention_mask must be [{B},{self.cfg.max_txt_len}]")
+        if B and (int(idx.min()) < 0 or int(idx.max()) >= kv.shape[0]):
+            raise IndexError("kv_index out of range")
+        fusion = torch.empty((B, E), dtype=torch.float32, device=self.device)
+        f16 = torch.empty((B, E), dtype=self.tdt, device=self.device)
+        for s in range(0, B, self.max_batch):
+            n = min(self.max_batch, B - s)
+            ws = self._workspace("qf", n)
+            L.check(self.lib.sprc_qformer_fuse_kv(C.byref(self.qf), kv.data_ptr(), kv.shape[1], idx[s:s + n].data_ptr(), ids[s:s + n].data_ptr(),
+                                                  mask[s:s + n].data_ptr(), n, fusion[s:s + n].data_ptr(), f16[s:s + n].data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), _stream(self.device)), "sprc_qformer_fuse_kv")
+        return fusion, f16
+
+    @_on_device
     def qformer_text(self, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         """feat[B,E] fp32 (unit rows) = normalize(text_proj(Qformer(text)[:, 0])): the Q-Former as a plain text encoder -- the
         stage-1 query feature of the rerank model class (blip2_qformer_cir_rerank.py:373-390)."""

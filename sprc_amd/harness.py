@@ -229,7 +229,37 @@ def extract_index_blip_features(dataset, blip_model, save_memory: bool = False, 
     return (torch.vstack(feats), torch.vstack(raws)), names
 
 
-def _stack_refs(name_to_feat: Dict[str, torch.Tensor], names: Sequence[str]) -> torch.Tensor:
+class ReferenceKVMap:
+    """name -> row of precomputed cross-attention K|V projections of the reference images (`build_reference_kv`): stands in for the
+    name -> raw-embedding dict of the prediction loops when `reuse_reference_kv` is on."""
+
+    def __init__(self, kv: torch.Tensor, rows: Dict[str, int]):
+        self.kv, self.rows = kv, rows
+
+    def get(self, name):
+        return self.rows.get(name)
+
+
+def build_reference_kv(blip_model, index_names: List[str], index_features, reference_names: Sequence[str]) -> ReferenceKVMap:
+    """K|V projections (Engine.encode_kv: Qformer.py:191-193 for all six cross-attention layers) of every DISTINCT reference image,
+    once: CIRR-val has 4181 queries over ~2000 distinct reference images, and the fusion pass otherwise projects a reference
+    image's 257 tokens once per query (6.7 of a query's 29.3 GFLOP).  4.7 MB per image in the 16-bit dtype."""
+    name_to_feat = dict(zip(index_names, index_features[1]))
+    uniq = list(dict.fromkeys(reference_names))
+    eng = blip_model.engine()
+    kv = torch.empty((len(uniq), eng.cfg.vit.tokens, eng.kv_width), dtype=eng.tdt, device=eng.device)
+    for s in range(0, len(uniq), 64):
+        eng.encode_kv(_stack_refs(name_to_feat, uniq[s:s + 64]).to(eng.device), out=kv[s:s + 64])
+    return ReferenceKVMap(kv, {n: i for i, n in enumerate(uniq)})
+
+
+def _stack_refs(name_to_feat, names: Sequence[str]):
+    if isinstance(name_to_feat, ReferenceKVMap):
+        from .model import ReferenceKV
+        rows = [name_to_feat.get(n) for n in names]
+        if any(r is None for r in rows):
+            raise KeyError("reference image without precomputed K|V projections")
+        return ReferenceKV(name_to_feat.kv, torch.tensor(rows, dtype=torch.int32))
     missing = [n for n in names if name_to_feat.get(n) is None]
     if missing:
         raise KeyError(f"no raw embeddings kept for reference image(s) {missing[:3]}: pass their names in `keep_raw`")
@@ -249,11 +279,12 @@ def _query_loader(dataset, batch_size: int, num_workers: int, **kw) -> DataLoade
 
 
 def generate_cirr_val_predictions(blip_model, relative_val_dataset, index_names: List[str], index_features, txt_processors,
-                                  batch_size: int = 32, num_workers: int = 2):
-    """-> (sim[nq,N], reference_names, target_names, group_members, captions)   (validate_blip.py:359-410)"""
+                                  batch_size: int = 32, num_workers: int = 2, reference_kv: Optional[ReferenceKVMap] = None):
+    """-> (sim[nq,N], reference_names, target_names, group_members, captions)   (validate_blip.py:359-410)
+    reference_kv (optional, `build_reference_kv`): the fusion pass reads precomputed K|V projections of the reference images."""
     print("Compute CIRR validation predictions")
     loader = _query_loader(relative_val_dataset, batch_size, num_workers, collate_fn=collate_fn)
-    name_to_feat = dict(zip(index_names, index_features[1]))
+    name_to_feat = reference_kv if reference_kv is not None else dict(zip(index_names, index_features[1]))
     sims, target_names, group_members, reference_names, captions_all = [], [], [], [], []
     dev = blip_model.device
     for batch_refs, batch_tgts, captions, batch_groups in tqdm(loader):
@@ -289,10 +320,17 @@ def cirr_metrics_from_sim(sim: torch.Tensor, ref_idx, tgt_idx, group_idx) -> Tup
             _pct(rank_t < 1), _pct(rank_t < 5), _pct(rank_t < 10), _pct(rank_t < 50))
 
 
-def compute_cirr_val_metrics(relative_val_dataset, blip_model, index_features, index_names: List[str], txt_processors):
-    """-> (group_recall@1, @2, @3, recall@1, @5, @10, @50)   (validate_blip.py:232-285)"""
+def compute_cirr_val_metrics(relative_val_dataset, blip_model, index_features, index_names: List[str], txt_processors,
+                             reuse_reference_kv: bool = False):
+    """-> (group_recall@1, @2, @3, recall@1, @5, @10, @50)   (validate_blip.py:232-285)
+    reuse_reference_kv (default off; 16-bit engines): project every distinct reference image's tokens to the cross-attention K|V once
+    (`build_reference_kv`) instead of once per query -- the same scores, 23 % fewer query-side flops."""
+    rkv = None
+    if reuse_reference_kv:
+        refs = [item[0] for item in (relative_val_dataset[i] for i in range(len(relative_val_dataset))) if item is not None]
+        rkv = build_reference_kv(blip_model, index_names, index_features, refs)
     sim, reference_names, target_names, group_members, _ = generate_cirr_val_predictions(
-        blip_model, relative_val_dataset, index_names, index_features, txt_processors)
+        blip_model, relative_val_dataset, index_names, index_features, txt_processors, reference_kv=rkv)
     print("Compute CIRR validation metrics")
     n2i = {n: i for i, n in enumerate(index_names)}
     ref = [n2i[n] for n in reference_names]

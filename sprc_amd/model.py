@@ -49,6 +49,19 @@ def _register(root: nn.Module, dotted: str, shape, device="cpu") -> None:
     mod.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape, device=device), requires_grad=not dotted.startswith("visual_encoder.")))
 
 
+class ReferenceKV:
+    """`reference_embeds` of `inference` as rows of precomputed cross-attention K|V projections (`Engine.encode_kv`) instead of raw ViT
+    embeddings: kv [n, 257, kv_width], index [B] = the row of each query's reference image.  Optional fast path of the evaluation harness
+    (`reuse_reference_kv`): an image that is the reference of several queries is projected once."""
+
+    def __init__(self, kv: torch.Tensor, index: torch.Tensor):
+        self.kv, self.index = kv, index
+        self.shape = (int(index.shape[0]),) + tuple(kv.shape[1:])
+
+    def to(self, *a, **k):
+        return self
+
+
 class Blip2QformerCirAlignPrompt(nn.Module):
     PRETRAINED_MODEL_CONFIG_DICT = {k: k for k in MODEL_TYPES}     # align_prompt.py:38-42 ("coco" has no CIR use)
 
@@ -149,6 +162,9 @@ class Blip2QformerCirAlignPrompt(nn.Module):
     @torch.no_grad()
     def fuse(self, reference_embeds: torch.Tensor, input_ids: torch.Tensor, attention_mask: torch.Tensor) -> torch.Tensor:
         """fusion_feats[B,256]: the query side of `inference` with pre-tokenised text."""
+        if isinstance(reference_embeds, ReferenceKV):
+            fusion, _ = self.engine().qformer_fuse_kv(reference_embeds.kv, reference_embeds.index, input_ids, attention_mask)
+            return fusion
         fusion, _ = self.engine().qformer_fuse(reference_embeds, input_ids, attention_mask)
         return fusion
 

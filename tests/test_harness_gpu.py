@@ -114,3 +114,50 @@ def test_model_protocol_and_cirr_loop_end_to_end():
     assert one.shape == (1, 12)
     with pytest.raises(ValueError):
         model.inference(raw[:2], feats, ["q0"])
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_reference_kv_reuse_gives_the_same_scores(dtype):
+    """Optional fast path (`compute_cirr_val_metrics(reuse_reference_kv=True)`, `blip_validate --reuse-reference-kv`; NOT used by bench.py):
+    every distinct reference image is projected to the Q-Former's cross-attention K|V once (sprc_qformer_encode_kv) and the fusion pass
+    of each query reads its row by index (sprc_qformer_fuse_kv) instead of projecting the image's 257 tokens again per query
+    (Qformer.py:191-193 inside align_prompt.py:332-339).  Same scores -- the projection is the same product on the same rows -- same
+    metrics; a query batch whose references repeat and arrive out of order exercises the index path of the attention kernel."""
+    cfg = get_config("pretrain", vit_depth=2)
+    model = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype=dtype, max_batch=16)
+    assert not model.load_state_dict(synth.make_state_dict(cfg, seed=21), strict=False).missing_keys
+    model = model.to(DEV).eval()
+    n_img, nq = 20, 37                                       # 37 queries over 7 distinct reference images, shuffled
+    images = synth.make_images(n_img, seed=22)
+
+    class Gal(Dataset):
+        def __len__(self):
+            return n_img
+
+        def __getitem__(self, i):
+            return f"img-{i:05d}", images[i]
+
+    (feats, raw), names = H.extract_index_blip_features(Gal(), model, batch_size=8, num_workers=0)
+    ids, mask, _ = synth.make_queries(nq, n_img, seed=23)
+    model.tokenizer = FakeTokenizer(ids, mask)
+    rng = np.random.default_rng(6)
+    ref = rng.choice([1, 4, 5, 9, 12, 17, 19], nq)
+    tgt = (ref + 1 + rng.integers(0, n_img - 1, nq)) % n_img
+    groups = np.stack([rng.permutation(np.array([ref[q], tgt[q], *[i for i in rng.permutation(n_img) if i not in (ref[q], tgt[q])][:4]]))
+                       for q in range(nq)])
+    rel = _Relative(ref, tgt, groups)
+    txt = {"eval": lambda c: c}
+    sim_a, *_ = H.generate_cirr_val_predictions(model, rel, names, (feats, raw), txt, num_workers=0)
+    rkv = H.build_reference_kv(model, names, (feats, raw), [f"img-{r:05d}" for r in ref])
+    assert rkv.kv.shape[0] == 7
+    sim_b, *_ = H.generate_cirr_val_predictions(model, rel, names, (feats, raw), txt, num_workers=0, reference_kv=rkv)
+    d = float((sim_a - sim_b).abs().max())
+    print(f"\n[reference K|V reuse, {dtype}] max |score difference| = {d:.1e} over {sim_a.numel()} scores; bit-identical: {torch.equal(sim_a, sim_b)}")
+    assert d < 2e-6
+    assert H.compute_cirr_val_metrics(rel, model, (feats, raw), names, txt, reuse_reference_kv=True) == \
+        H.compute_cirr_val_metrics(rel, model, (feats, raw), names, txt)
+    with pytest.raises(ValueError):                          # the exact-fp32 engine recomputes its projections: no kv path
+        m32 = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=16)
+        m32.load_state_dict(synth.make_state_dict(cfg, seed=21), strict=False)
+        m32 = m32.to(DEV).eval()
+        m32.engine().qformer_fuse_kv(rkv.kv.float(), torch.zeros(2, dtype=torch.int32), ids[:2], mask[:2])
