@@ -6,7 +6,7 @@ workload: BASELINE.json configs[1] -- "CIRR-val full gallery (~2k), ViT-g bf16, 
           a 2297-image gallery and 4181 composed queries (CIRR-val sizes).
 step    : one pass of the hot path over one batch of synthetic input =
             encode 128 gallery images   (ViT-g/14, 39 blocks -> ln_vision -> Q-Former -> vision_proj -> L2 norm),
-            fuse   232 composed queries (128 * 4181/2297: Q-Former pass 1 + pass 2 -> text_proj -> L2 norm),
+            fuse   233 composed queries (ceil(128 * 4181/2297): Q-Former pass 1 + pass 2 -> text_proj -> L2 norm),
             rank   them against the FULL resident 2297-image gallery (max-over-32 cosine similarity, top-51).
           value = images processed by all ranks / wall time; inputs are resident in HBM before the timed region.
 N > 1   : weak scaling, one rank per GPU: every rank owns a 2297-image gallery shard and its own queries; the only
@@ -78,10 +78,15 @@ def parse():
     ap.add_argument("--qf-streams", type=int, default=2, help="2 = the gallery-side and the query-side Q-Former passes of a step run on two streams")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = batch i's Q-Former passes and ranking overlap batch i+1's ViT (side streams, raw embeddings "
                     "double-buffered); instrumented steps (--prof-every) stay serialised")
-    ap.add_argument("--recall", action="store_true", help="after the timed region: Recall@1/5/10/50 + subset recalls of the benchmarked engine on the "
-                    "planted-structure CIRR-val-sized case (2297 images x 4181 queries, sprc_amd/planted.py) next to the exact-fp32 engine's on the "
-                    "same targets -> a `recall` object in the line (~1 min; synthetic weights: the real checkpoint is a network fetch)")
+    ap.add_argument("--no-recall", action="store_true", help="skip the `recall` object (default ON at N = 1: after the timed region, Recall@1/5/10/50 + subset "
+                    "recalls of the benchmarked engine on the planted-structure CIRR-val-sized case next to the UNMODIFIED REFERENCE's own scores for "
+                    "every 22nd query of that case -- 191 queries x 2297 images, tests/golden/planted_c2_subset_eva*.npz; ~40 s; synthetic weights: "
+                    "the real checkpoint is a network fetch)")
+    ap.add_argument("--recall", action="store_true", help="(accepted for compatibility: the recall object is on by default)")
     ap.add_argument("--cpu-images", type=int, default=32, help="size of the bounded CPU-baseline sample (~15 s of CPU work on 16 cores)")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full"], help="full: ONLY run SURVEY.md section 8(d)'s CPU-baseline procedure -- config C1's "
+                    "sizes (256 gallery images, 64 queries), one warm-up + best of 3, all host cores (~10 min) -- print it as one JSON line and write "
+                    "gpurun_out/cpu_baseline_c1.json; no GPU work, no bench line (once per round -> profiles/rNN_cpu_baseline_c1.json)")
     return ap.parse_args()
 
 
@@ -133,6 +138,40 @@ def cpu_baseline(cfg, n_img: int):
                       f"of CPU time, outside the bench's budget): oracle fp32 (torch CPU, {cores} threads on {cpu_model}): encode {n_img} "
                       f"images {t1 - t0:.1f}s + fuse/rank {nq} queries vs {n_img} images {t2 - t1:.1f}s; value = 1 / (s per image + "
                       f"{QUERIES}/{GALLERY} x s per query)"}
+
+
+def cpu_baseline_full(cfg, n_img: int = 256, nq: int = 64, reps: int = 3):
+    """SURVEY.md section 8(d)'s procedure as written: config C1's sizes, `torch.set_num_threads(usable cores)`, one warm-up pass over a
+    16-image batch, then `reps` timed passes; best-of-`reps` for the encode and the fuse + rank halves separately and combined."""
+    from oracle import sprc_oracle as O
+    from sprc_amd import synth
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    cpu_model = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.lower().startswith("model name")), "unknown")
+    sd = synth.make_state_dict(cfg, seed=0)
+    images = synth.make_images(n_img, seed=0)
+    ids, mask, ref = synth.make_queries(nq, n_img, seed=1)
+    enc, fr = [], []
+    with torch.no_grad():
+        O.extract_target_features(sd, cfg, images[:16])
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            parts = [O.extract_target_features(sd, cfg, images[s:s + 32]) for s in range(0, n_img, 32)]
+            feats, raw = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+            t1 = time.perf_counter()
+            sim = O.inference(sd, cfg, raw[ref], feats, ids, mask)
+            O.topk_stable(sim.numpy(), min(TOPK, n_img))
+            t2 = time.perf_counter()
+            enc.append(t1 - t0)
+            fr.append(t2 - t1)
+            print(f"  pass: encode {n_img} images {t1 - t0:.1f}s, fuse + rank {nq} queries {t2 - t1:.1f}s", file=sys.stderr, flush=True)
+    e, f = min(enc), min(fr)
+    per_img = e / n_img + f / nq * (QUERIES / GALLERY)
+    return {"procedure": "SURVEY.md section 8(d): config C1 sizes, one warm-up, best of %d" % reps, "kind": "port", "cores": cores, "cpu_model": cpu_model,
+            "gallery_images": n_img, "queries": nq, "encode_s_per_pass": [round(x, 2) for x in enc], "fuse_rank_s_per_pass": [round(x, 2) for x in fr],
+            "encode_images_per_s": round(n_img / e, 4), "fuse_rank_queries_per_s": round(nq / f, 3),
+            "value": round(1.0 / per_img, 4), "unit": "images/s",
+            "combined": f"1 / (s per image + {QUERIES}/{GALLERY} x s per query): the workload's query : image ratio"}
 
 
 def respawn(n: int) -> int:
@@ -224,6 +263,14 @@ def c5_slice(a, dev, rank, world):
 
 def main():
     a = parse()
+    if a.cpu_baseline == "full":
+        from sprc_amd.config import get_config
+        out = cpu_baseline_full(get_config(a.backbone))
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "cpu_baseline_c1.json"), "w") as f:
+            json.dump(out, f, indent=1)
+        print(json.dumps(out), flush=True)
+        return
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -469,22 +516,25 @@ def main():
                          "executed_tflops": round(pe.exec_flops / max(pe.busy_ms, 1e-9) / 1e9, 1)},
             "kernels": kernels,
         }
-        if a.recall and a.backbone == "pretrain" and a.dtype in ("fp16", "bf16", "fp32"):
-            # BASELINE.json's metric names Recall@K next to the throughput: measured on planted-structure weights / images at CIRR-val's
-            # sizes, targets at planned ranks of the exact-fp32 engine's ordering (the fp32 engine is within 5e-6 of the reference's scores
-            # on every reference-generated golden, incl. 438 727 scores of this very case: tests/test_configs_gpu.py)
+        if not a.no_recall and world == 1 and a.backbone == "pretrain" and a.dtype in ("fp16", "bf16", "fp32"):
+            # BASELINE.json's metric names Recall@K next to the throughput ("Recall@1/5/10 equal to reference on CIRR-val").  No checkpoint and no
+            # dataset offline: planted-structure weights / images at CIRR-val's sizes; the yardstick is the scores the unmodified reference
+            # produced itself (CPU fp32) for every 22nd query of that case, on fp32-valued weights and on fp16-valued trunk weights (what a
+            # GPU-trained reference checkpoint holds) -- fixtures under tests/golden/, generated by oracle/gen_c2_subset.py
             from sprc_amd import planted as P
             del eng
             torch.cuda.empty_cache()
-            sdp = synth.make_state_dict(cfg, seed=5, planted=True)
-            s_ref, refq = P.planted_scores(cfg, sdp, dev, "fp32")
-            s_eng, _ = P.planted_scores(cfg, sdp, dev, a.dtype)
-            rep = P.recall_report(s_ref, s_eng, refq)
-            out["recall"] = {"engine": rep["engine"], "fp32_engine_as_reference": rep["reference_order"],
-                             "equal_recall_at_1_5_10": all(rep["engine"][k] == rep["reference_order"][k] for k in ("recall_at_1", "recall_at_5", "recall_at_10")),
-                             "max_abs_dsim": rep["max_abs_dsim"], "rms_dsim": rep["rms_dsim"], "top1_image_equal_pct": rep["top1_image_equal_pct"],
-                             "case": f"planted-structure synthetic weights and images, {P.N_GALLERY} gallery x {P.N_QUERIES} queries (CIRR-val sizes), full depth, "
-                                     f"engine dtype {a.dtype}; targets at planned ranks of the fp32 engine's ordering"}
+            imgs = list(P.planted_images())
+            out["recall"] = {"case": f"planted-structure synthetic weights and images, {P.N_GALLERY} gallery images (CIRR-val's size), every 22nd of "
+                                     f"{P.N_QUERIES} composed queries, full depth, engine dtype {a.dtype}; targets at planned ranks of the REFERENCE's ordering; "
+                                     "reference = the unmodified reference's CPU fp32 scores (tests/golden/planted_c2_subset_eva*.npz)"}
+            for key, fn in (("fp32_weights", "planted_c2_subset_eva.npz"), ("fp16_valued_trunk", "planted_c2_subset_eva_h16.npz")):
+                gp = os.path.join(ROOT, "tests", "golden", fn)
+                if os.path.exists(gp):
+                    out["recall"][key] = P.reference_subset_report(cfg, dev, a.dtype, gp, images=imgs)
+            subs = [v for v in out["recall"].values() if isinstance(v, dict)]
+            out["recall"]["equal_recall_at_1_5_10"] = bool(subs) and all(v["equal_recall_at_1_5_10"] for v in subs)
+            del imgs
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_images)
         print(json.dumps(out), flush=True)

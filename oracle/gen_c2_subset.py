@@ -6,6 +6,10 @@ TEST INFRASTRUCTURE.  tests/test_configs_gpu.py compares the fp16 engine with th
 engine is 5e-6 from the reference on every golden); this fixture lets the same test state the engine's error at that size against scores
 the unmodified reference produced itself.  Weights, images and queries are drawn exactly as the test draws them
 (seed 5 / per-batch image seeds 1000 + s / query seed 6).  ~35 min on 8 cores.
+
+`--h16` writes planted_c2_subset_eva_h16.npz: the same case on a checkpoint whose trunk weights are fp16-VALUED (what a GPU-trained
+reference checkpoint holds: eva_vit.py:410-425 converts the ViT to fp16 before training; blip2.py:36-44) -- the case on which the fp16
+engine is held to a flat 1e-3 at the benchmarked size.
 """
 from __future__ import annotations
 
@@ -28,9 +32,10 @@ N, NQ, STEP = 2297, 4181, 22
 
 
 def main():
-    torch.set_num_threads(8)
+    h16 = "--h16" in sys.argv                            # fp16-VALUED trunk weights: what a GPU-trained reference checkpoint holds
+    torch.set_num_threads(int(next((a.split("=")[1] for a in sys.argv if a.startswith("--threads=")), 8)))
     cfg = get_config("pretrain")
-    sd = synth.make_state_dict(cfg, seed=5, planted=True)
+    sd = synth.make_state_dict(cfg, seed=5, planted=True, trunk_fp16=h16)
     model = ref_import.build_reference_model(cfg, sd)
     g = torch.Generator().manual_seed(5)
     basis = torch.randn((8, 3, 224, 224), generator=g)
@@ -60,8 +65,8 @@ def main():
             rr = torch.stack([raws[int(r)] for r in ref[q]])
             sims.append(model.inference(rr, feats, ["caption"] * len(q)))
     sim = torch.cat(sims).numpy().astype(np.float32)
-    out = ROOT / "tests" / "golden" / "planted_c2_subset_eva.npz"
-    np.savez_compressed(out, model_type="pretrain", vit_depth=cfg.vit.depth, seed=5, n_img=N, n_q=NQ, query_step=STEP,
+    out = ROOT / "tests" / "golden" / ("planted_c2_subset_eva_h16.npz" if h16 else "planted_c2_subset_eva.npz")
+    np.savez_compressed(out, model_type="pretrain", vit_depth=cfg.vit.depth, seed=5, n_img=N, n_q=NQ, query_step=STEP, trunk_fp16=int(h16),
                         query_index=qsel.numpy(), ref_index=ref[qsel].numpy(), sim=sim, feats_probe=feats[::256, :2].numpy())
     print(f"wrote {out}: sim {sim.shape} range [{sim.min():.3f}, {sim.max():.3f}]  ({time.time() - t0:.0f}s)")
 

@@ -144,13 +144,14 @@ def drop_site(pass_id: int, layer: int, kind: int) -> int:
 
 def drop_keep(seed: int, site: int, n: int, p: float) -> np.ndarray:
     """keep mask [n] (bool) of dropout site `site`: z = seed + site * 0x9E3779B97F4A7C15 + i * 0xD1B54A32D192ED03 (mod 2^64),
-    SplitMix64 finaliser, keep <=> (z >> 32) >= floor(p * 2^32)."""
+    SplitMix64 finaliser, keep <=> (z >> 32) >= floor(fl32(p) * 2^32) -- p is taken as the FLOAT32 the C ABI carries (sprc.h: drop_p is a
+    float; csrc/common.hpp: drop_thresh), so that both sides form the same threshold: 0.1 -> 429496736 (the double 0.1 gives 429496729)."""
     with np.errstate(over="ignore"):
         z = np.uint64(seed % (1 << 64)) + np.uint64(site) * np.uint64(0x9E3779B97F4A7C15) + np.arange(n, dtype=np.uint64) * np.uint64(0xD1B54A32D192ED03)
         z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
         z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
         z ^= z >> np.uint64(31)
-    return (z >> np.uint64(32)) >= np.uint64(int(p * 4294967296.0))
+    return (z >> np.uint64(32)) >= np.uint64(int(float(np.float32(p)) * 4294967296.0))
 
 
 def dropout(x: Tensor, drop, site: int) -> Tensor:
@@ -159,7 +160,7 @@ def dropout(x: Tensor, drop, site: int) -> Tensor:
         return x
     seed, p = drop[0], drop[1]
     keep = torch.from_numpy(drop_keep(seed, site, x.numel(), p)).view(x.shape)
-    return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
+    return x * keep.to(x.dtype) * float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))      # the kernels' fp32 1 / (1 - p)
 
 
 def _bert_attention(sd: SD, pre: str, x_q: Tensor, x_kv: Tensor, add_mask: Optional[Tensor],

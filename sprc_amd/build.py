@@ -9,7 +9,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = Path(__file__).resolve().parent / "libsprc_hip.so"
-SOURCES = ["gemm.hip", "gemm_f16.hip", "gemm_f16e.hip", "gemm_fp8.hip", "gemm_f32.hip", "core.hip", "attention.hip", "rowops.hip", "rank.hip", "models.hip", "preprocess.hip", "train.hip"]
+SOURCES = ["gemm.hip", "gemm_f16.hip", "gemm_f16e.hip", "gemm_duo.hip", "gemm_fp8.hip", "gemm_f32.hip", "core.hip", "attention.hip", "rowops.hip", "rank.hip", "models.hip", "preprocess.hip", "train.hip"]
 # -fno-slp-vectorize: hipcc packs adjacent scalar fp32 ops into v_pk_fma_f32 / v_pk_mul_f32, which run SLOWER than the scalar
 # pairs on gfx950 (measured on the GEMM GELU epilogue: 117 us packed vs ~45 us scalar per ViT fc1 launch)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
@@ -32,7 +32,7 @@ def build(force: bool = False, verbose: bool = True, always: tuple = ()) -> Path
     hipcc = _hipcc()
     objdir = CSRC / "build"
     objdir.mkdir(exist_ok=True)
-    headers = [CSRC / "common.hpp", CSRC / "gemm_impl.hpp", CSRC.parent.parent / "include" / "sprc.h"]
+    headers = [CSRC / "common.hpp", CSRC / "gemm_impl.hpp", CSRC / "gemm_duo.hpp", CSRC.parent.parent / "include" / "sprc.h"]
 
     def compile_one(src: str):
         obj = objdir / (src + ".o")

@@ -72,6 +72,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     p.w_scale = a->dtype == SPRC_FP8 ? a->w_scale : nullptr; p.a_scale = a->a_scale; p.out_scale = a->out_scale;
     static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
     p.debug = dbg;
+    p.duo_sleep = 0; p.duo_ctr = nullptr;
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     p.k8 = a->k8;
     hipStream_t st = (hipStream_t)s;

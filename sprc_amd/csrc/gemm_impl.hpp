@@ -58,6 +58,8 @@ struct GemmParams {
     int debug;                          // SPRC_GEMM_DEBUG on the 256x256 kernel: 64 s_memtime stamp build (tools/gemm_stamp.py)
     int k8;                             // MIX kernels (split-precision products): e4m3 reduction elements that FOLLOW the K fp16 elements in
                                         // every row of A and W (K-tiles of 128 bytes either way); their partial sum enters scaled by 2^-18
+    int duo_sleep;                      // duo kernel (gemm_duo.hpp): cycles the second workgroup of a CU sleeps before its first tile (0: no stagger)
+    int* duo_ctr;                       // duo kernel: per-CU arrival counters (DUO_CTRS ints, only ever incremented)
 };
 
 // MX block scales of the split-precision products' e4m3 segments: E8M0 118 = 2^-9 on BOTH operands -> 2^-18 on the product, the
@@ -93,7 +95,6 @@ __device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, b
     return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
 }
 // 4 consecutive outputs of one row: 16 B (fp32) or 8 B (bf16 / fp16)
-// n_split: logical row width N (SPRC_F16X3 outputs only: the lo / second-hi copies sit N and 2N elements further)
 // n_split / col: logical row width N and this quad's first column (SPRC_F16X3 outputs only: the e4m3 segments sit behind the N fp16 values)
 template <typename OutT>
 __device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v, int n_split = 0, int col = 0) {
@@ -1072,6 +1073,10 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     return SPRC_OK;
 }
 
+// duo kernel (gemm_duo.hpp; its instantiations live in gemm_duo.hip): 16-bit operands, out kind 0 = the operands' 16-bit type, 1 = fp32,
+// 2 = SPRC_F16X3 split rows (fp16 operands).  SPRC_EUNSUPPORTED: no such instantiation -- the caller falls back to the other kernels.
+int gemm_duo_launch(bool f16, int out_kind, int act, const GemmParams& p, hipStream_t st);
+
 // The kernels address a tile with 32-bit offsets from its first row: the rows of one (<= 256-row) tile must span < 4 GiB.
 static bool fits_u32(const GemmParams& p) {
     const int64_t span_a = p.a_shift < 0 ? 256 : (int64_t)((256 >> p.a_shift) + 2) * p.a_stride;
@@ -1085,6 +1090,14 @@ static int launch(const GemmParams& p, hipStream_t st) {
     static const int forced = env_int("SPRC_GEMM_TILE", 0);
     const int keff = MIX ? p.K + p.k8 / 2 : p.K;                // reduction length in units of 16-bit elements (time ~ bytes of a row)
     int cfg = forced;
+    if constexpr (sizeof(T) == 2 && !MAX32 && !MIX && !std::is_same<OutT, fp8_t>::value) {
+        static const int duo = env_int("SPRC_GEMM_DUO", 0);       // 1: every eligible product on the duo kernel (A/B switch)
+        if (duo == 1 && p.ksplit <= 1 && p.K % 32 == 0) {
+            constexpr int ok = std::is_same<OutT, float>::value ? 1 : std::is_same<OutT, f16x3_t>::value ? 2 : 0;
+            const int rc = gemm_duo_launch(std::is_same<T, f16_t>::value, ok, ACT, p, st);
+            if (rc != SPRC_EUNSUPPORTED) return rc;
+        }
+    }
     if constexpr (sizeof(T) <= 2) {
         if (cfg == 0) {
             // Cost model in units of one 256x256xK tile on a CU (measured on MI355X, tools/gemm_shapes.py):

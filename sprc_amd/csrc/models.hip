@@ -28,25 +28,8 @@ struct Fp8Scales { const float* w_scale; float a_scale, out_scale; };
 static int gemm(hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
                 void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0,
                 sprc_rowmap amap = ID_MAP, sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0,
-                const Fp8Scales* q = nullptr, int64_t ldw = 0, int k8 = 0) {
-    sprc_gemm_args g;
-    memset(&g, 0, sizeof(g));
-    g.k8 = k8;
-    if (q != nullptr) { g.w_scale = q->w_scale; g.a_scale = q->a_scale; g.out_scale = q->out_scale; }
-    g.M = M; g.N = N; g.K = K; g.dtype = dt; g.out_dtype = out_dt; g.act = act;
-    g.A = A; g.lda = lda; g.amap = amap;
-    g.W = w.w; g.ldw = ldw > 0 ? ldw : K; g.bias = w.b;
-    g.resid = resid; g.ldr = ldr;
-    g.C = C; g.ldc = ldc; g.cmap = cmap;
-    g.scratch = scratch; g.scratch_bytes = scratch_bytes;
-    return sprc_gemm(&g, st);
-}
-
-// the same with an algorithmic reduction length for the profiler (the patch embedding launches its zero-padded K)
-static int gemm_ka(int k_alg, hipStream_t st, int dt, int out_dt, int M, int N, int K, const void* A, int64_t lda, const sprc_linear& w,
-                   void* C, int64_t ldc, int act = SPRC_ACT_NONE, const float* resid = nullptr, int64_t ldr = 0, sprc_rowmap amap = ID_MAP,
-                   sprc_rowmap cmap = ID_MAP, void* scratch = nullptr, size_t scratch_bytes = 0, const Fp8Scales* q = nullptr, int64_t ldw = 0,
-                   int k8 = 0) {
+                const Fp8Scales* q = nullptr, int64_t ldw = 0, int k8 = 0, int k_alg = 0) {
+    // k_alg: the ALGORITHMIC reduction length for the profiler when it differs from K (the patch embedding launches its zero-padded K)
     sprc_gemm_args g;
     memset(&g, 0, sizeof(g));
     g.k8 = k8; g.k_alg = k_alg;
@@ -364,11 +347,12 @@ extern "C" int sprc_vit_forward(const sprc_vit_model* m, const float* images, in
     const int patch_k = 3 * m->patch_size * m->patch_size;     // the convolution's own reduction length (588; launched zero padded)
     if (m->patch_x3) {                                      // split-precision patch embedding: fp16 product + e4m3 correction segments
         RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, SPRC_F16X3, st));
-        RUN(gemm_ka(patch_k, st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, 2 * m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP,
-                    ID_MAP, nullptr, 0, nullptr, 2 * m->patch_k_pad, 2 * m->patch_k_pad));
+        RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, 2 * m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP,
+                 ID_MAP, nullptr, 0, nullptr, 2 * m->patch_k_pad, 2 * m->patch_k_pad, patch_k));
     } else {
         RUN(sprc_im2row(images, v.rows, B, m->image, m->patch_size, m->patch_k_pad, dt, st));
-        RUN(gemm_ka(patch_k, st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D));
+        RUN(gemm(st, dt, SPRC_F32, P, D, m->patch_k_pad, v.rows, m->patch_k_pad, m->patch, v.pout, D, SPRC_ACT_NONE, nullptr, 0, ID_MAP, ID_MAP,
+                 nullptr, 0, nullptr, 0, 0, patch_k));
     }
     RUN(sprc_vit_assemble(v.pout, m->cls, m->pos, v.x, B, T, D, st));
     if (m->has_ln_pre) RUN(lnorm(st, dt, M, D, v.x, m->ln_pre_w, m->ln_pre_b, m->ln_eps, v.x, nullptr));

@@ -144,3 +144,23 @@ class ShardedRanker:
             return mv, mi
         ls = got[:, :, 2 * k:].contiguous().view(torch.float32).max(dim=0).values               # exactly one owner per item
         return mv, mi, ls
+
+
+def rank_logical_shards(feats: torch.Tensor, fusion: torch.Tensor, k: int, shards: int, sim_fn: SimFn = _hip_sim, topk_fn: TopkFn = _hip_topk,
+                        sim_budget_bytes: int = 2 << 30):
+    """ONE process, `shards` logical gallery shards (contiguous slices under `shard_bounds`): every shard is ranked by its own ShardedRanker
+    (blocks of query rows, top-k per shard) and the shards' candidates are merged exactly as exchange 2 of `ShardedRanker.rank` merges the
+    all_gather'ed payloads (k x shards candidates per query, integer keys) -- the 8-GPU data flow of BASELINE config C5 without the
+    collectives.  -> (sim[nq,k], global idx[nq,k]), bit-identical to a global pass over the whole gallery."""
+    n = feats.shape[0]
+    cand_v, cand_i = [], []
+    for r in range(shards):
+        lo, hi = shard_bounds(n, shards, r)
+        v, i = ShardedRanker(feats[lo:hi], index_base=lo, sim_fn=sim_fn, topk_fn=topk_fn, always_exchange=False,
+                             sim_budget_bytes=sim_budget_bytes).rank(fusion, k)
+        cand_v.append(v)
+        cand_i.append(i)
+    cv, ci = torch.cat(cand_v, 1).contiguous(), torch.cat(cand_i, 1).contiguous()
+    ci = torch.where(ci < 0, torch.full_like(ci, 2**31 - 1), ci)
+    mv, mi = topk_fn(cv, k, ci, 0)
+    return mv, torch.where(torch.isinf(mv) & (mv < 0), torch.full_like(mi, -1), mi)

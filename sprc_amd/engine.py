@@ -55,6 +55,7 @@ def rowmap(rows_per_group: int = 0, group_stride: int = 0, group_offset: int = 0
 # thin operator wrappers (used by the unit parity tests and by Engine)
 # ---- the split-precision row layout (sprc.h: SPRC_F16X3), restated with torch ops: what the producers' kernels write ---------------
 SPLIT_LO_SHIFT, SPLIT_W_SHIFT, SPLIT_WLO_SHIFT = 12, 6, 18        # [x_lo 2^12 | x] . [W 2^6 | W_lo 2^18], product scaled by 2^-18
+SPLIT_W_ABSMAX, SPLIT_X_ABSMAX = 3.5, 224.0                       # beyond these the e4m3 correction segments saturate (see Engine._split_rows)
 
 
 def _e4m3_bytes(t: torch.Tensor) -> torch.Tensor:
@@ -304,6 +305,16 @@ class Engine:
     def _split_rows(self, w32: torch.Tensor) -> torch.Tensor:
         """[out, in] fp32 -> the weight side of a split-precision product (sprc.h: SPRC_F16X3), uint8 [out, 4 in]:
         [ in x fp16: W_hi | in x e4m3: W * 2^6 | in x e4m3: (W - W_hi) * 2^18 ]."""
+        # the e4m3 correction segments SATURATE at +-448: W 2^6 clips for |W| > 7, (W - W_hi) 2^18 for |W| > ~3.5 (half an fp16 ulp of
+        # 4 .. 8 is 2^-9).  Past that the correction terms are wrong and the product silently falls back to plain-fp16 accuracy, so the
+        # range is checked when the weights are packed (ADVICE r4).  Activation side (the producers' kernels, common.hpp: store_split4):
+        # the residual (x - x_hi) 2^12 clips for |x| > ~224, x itself for |x| > 448 -- LayerNorm outputs and GELU hiddens of a trained
+        # Q-Former are O(1 .. 30); SPRC_X3_CHECK=1 makes split_rows_checked() test an activation tensor in debug runs.
+        amax = float(w32.abs().max()) if w32.numel() else 0.0
+        if amax > SPLIT_W_ABSMAX:
+            import warnings
+            warnings.warn(f"split-precision weight rows: |W| max {amax:.3g} exceeds {SPLIT_W_ABSMAX} -- the e4m3 correction segments saturate "
+                          "and this layer's products fall back to plain fp16 accuracy (pack the layer without its X3_* bit, or rescale it)", RuntimeWarning)
         rows = split_rows(w32, weight=True)
         assert rows.shape == (w32.shape[0], 2 * w32.shape[1])
         self._keep.append(rows)
@@ -318,8 +329,8 @@ class Engine:
         return L.Linear(rows.data_ptr(), None if b is None else self._f32(b).data_ptr())
 
     def _lin_patch(self, w: torch.Tensor, b: Optional[torch.Tensor]) -> L.Linear:
-        """The patch embedding's weights [width, 3 P P] padded to patch_k_pad columns; fp16 engine: split precision, [W_hi | W_hi | W_lo]
-        (sprc_vit_model.patch_x3: the embedding's output is the first value of the residual stream, its rounding error is never averaged away)."""
+        """The patch embedding's weights [width, 3 P P] padded to patch_k_pad columns; fp16 engine: split precision
+        (sprc_vit_model.patch_x3; rows [W_hi | W 2^6 | W_lo 2^18] as every split weight: the embedding's output is the first value of the residual stream, its rounding error is never averaged away)."""
         if not self.patch_x3:
             return self._lin(w, b, self.patch_k_pad)
         w32 = torch.nn.functional.pad(w.detach().to(device=self.device, dtype=torch.float32), (0, self.patch_k_pad - w.shape[1]))

@@ -247,6 +247,13 @@ def build_reference_kv(blip_model, index_names: List[str], index_features, refer
     name_to_feat = dict(zip(index_names, index_features[1]))
     uniq = list(dict.fromkeys(reference_names))
     eng = blip_model.engine()
+    if not eng.is16:                             # (checked BEFORE the allocation: the fused-K|V entry point exists for the 16-bit engines only)
+        raise ValueError("reuse_reference_kv needs a 16-bit engine (fp16 / bf16): sprc_qformer_fuse_kv is not built for the fp32 parity engine")
+    need = len(uniq) * eng.cfg.vit.tokens * eng.kv_width * torch.empty((), dtype=eng.tdt).element_size()
+    free = torch.cuda.mem_get_info(eng.device)[0]
+    if need > 0.8 * free:                        # ~4.7 MB per distinct reference image (9.5 GB for CIRR-val): refuse rather than thrash
+        raise MemoryError(f"reuse_reference_kv: the K|V cache of {len(uniq)} distinct reference images needs {need / 2**30:.1f} GiB, "
+                          f"{free / 2**30:.1f} GiB are free -- evaluate without reuse_reference_kv, or in query chunks")
     kv = torch.empty((len(uniq), eng.cfg.vit.tokens, eng.kv_width), dtype=eng.tdt, device=eng.device)
     for s in range(0, len(uniq), 64):
         eng.encode_kv(_stack_refs(name_to_feat, uniq[s:s + 64]).to(eng.device), out=kv[s:s + 64])

@@ -227,8 +227,11 @@ class Blip2QformerCirAlignPrompt(nn.Module):
         return prob.view(nq, T)
 
     def forward(self, samples):
-        """Training step, align_prompt.py:95-200: {"image", "target", "text_input"} -> {"loss_itc", "loss_rtc", "loss_align"}, eval
-        semantics (dropout = identity).  With autograd enabled the losses are outputs of a torch.autograd.Function whose backward
+        """Training step, align_prompt.py:95-200: {"image", "target", "text_input"} -> {"loss_itc", "loss_rtc", "loss_align"}.
+        Dropout: with autograd enabled AND the module in train mode (`model.train()`, the nn.Module default) the Q-Former's dropout runs
+        (p = 0.1 at Qformer.py:113,264,293,379; counter-based masks, regenerated in backward); in eval mode, and under torch.no_grad() in
+        EITHER mode, dropout is the identity -- no_grad means "measure the losses", as the reference's validation does under model.eval().
+        With autograd enabled the losses are outputs of a torch.autograd.Function whose backward
         runs the HIP backward kernels (sprc_amd/train.py) and hands every trainable parameter its gradient, so the reference's loop
         (blip_fine_tune_2.py:293-304: weighted sum, `scaler.scale(loss).backward()`, AdamW step) runs as written; the training graph
         is evaluated on the exact-fp32 engine.  Under torch.no_grad() the losses come from the inference engine in its compute dtype."""

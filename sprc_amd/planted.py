@@ -4,7 +4,8 @@
 There is no checkpoint and no dataset offline, so "Recall@K on CIRR-val" (BASELINE.json's metric) is measured on seeded synthetic
 weights with planted structure (synth.plant_structure: scores spread over ~1.0) and planted images, with each query's target placed at
 a planned rank of a REFERENCE ordering (the exact-fp32 engine's, which is 5e-6 from the reference's scores on every reference-generated
-golden; tests/golden/planted_c2_subset_eva.npz holds the unmodified reference's own scores for every 22nd query of this very case).
+golden; tests/golden/planted_c2_subset_eva.npz holds the unmodified reference's own scores for every 22nd query of this very case, and
+`reference_subset_report` -- the `recall` object of the bench line -- compares the engine with THOSE).
 Everything here runs on the HIP engine; nothing imports the oracle.
 """
 from __future__ import annotations
@@ -35,14 +36,19 @@ def planted_images(n: int = N_GALLERY, seed: int = 5):
 
 
 def planted_scores(cfg: SprcConfig, sd: Dict[str, torch.Tensor], device, dtype: str, n: int = N_GALLERY, nq: int = N_QUERIES,
-                   seed: int = 5) -> Tuple[torch.Tensor, np.ndarray]:
+                   seed: int = 5, query_index=None, images=None) -> Tuple[torch.Tensor, np.ndarray]:
     """sim[nq, n] of the `dtype` engine on the planted case (weights `sd` = synth.make_state_dict(cfg, seed, planted=True)), and the
-    queries' reference indices."""
+    queries' reference indices.  query_index: only these of the nq queries (rows of sim / entries of ref in that order);
+    images: a materialised list(planted_images(n, seed)) to share between several engines."""
     ids, mask, ref = synth.make_queries(nq, n, seed=seed + 1)
     ref = ref.numpy()
+    if query_index is not None:
+        qi = np.asarray(query_index, dtype=np.int64)
+        ids, mask, ref = ids[torch.from_numpy(qi)], mask[torch.from_numpy(qi)], ref[qi]
+        nq = len(qi)
     eng = E.Engine(cfg, sd, device, dtype=dtype, max_batch=233)
     feats, raws = [], []
-    for s, img in planted_images(n, seed):
+    for s, img in (images if images is not None else planted_images(n, seed)):
         raw = eng.vit_forward(img.to(device))
         feats.append(eng.qformer_image(raw)[0])
         raws.append(raw.to(torch.float16) if dtype == "fp16" else raw)            # (the fp16 engine rounds them to fp16 anyway)
@@ -97,3 +103,28 @@ def recall_report(sim_ref: torch.Tensor, sim_eng: torch.Tensor, ref: np.ndarray)
             "max_abs_dsim": float(d.max()), "rms_dsim": float(d.pow(2).mean().sqrt()),
             "dsim_quantiles_50_99_99.9_99.99": [float(x) for x in q],
             "metrics_ref": [float(x) for x in m_ref], "metrics_eng": [float(x) for x in m_eng], "tgt": tgt, "groups": groups}
+
+
+def reference_subset_report(cfg: SprcConfig, device, dtype: str, golden_path, images=None) -> dict:
+    """The bench line's `recall` object (BASELINE.json's metric: "... + Recall@1/5/10, CIRR-val"; validate_blip.py:255-285): the engine
+    against scores the UNMODIFIED REFERENCE produced on its CPU fp32 path for every 22nd query of the planted CIRR-val-sized case
+    (191 queries x 2297 images; the fixture is data generated by oracle/gen_c2_subset.py, read here like any dataset file).  Targets are
+    planned on the REFERENCE's ordering; both score matrices go through the same metric code (harness.cirr_metrics_from_sim, integer-exact
+    against the oracle in tests/)."""
+    g = np.load(golden_path, allow_pickle=False)
+    n, nq, qi = int(g["n_img"]), int(g["n_q"]), g["query_index"]
+    h16 = bool(int(g["trunk_fp16"])) if "trunk_fp16" in g.files else False
+    sd = synth.make_state_dict(cfg, seed=int(g["seed"]), planted=True, trunk_fp16=h16)
+    s_eng, ref = planted_scores(cfg, sd, device, dtype, n=n, nq=nq, seed=int(g["seed"]), query_index=qi, images=images)
+    assert np.array_equal(ref, g["ref_index"]), "fixture and engine disagree on the queries' reference images"
+    s_ref = torch.from_numpy(g["sim"]).to(device)
+    rep = recall_report(s_ref, s_eng, ref)
+    o_ref, o_eng = E.topk(s_ref.contiguous(), 10)[1], E.topk(s_eng.contiguous(), 10)[1]      # the library's stable top-k (rank.hip)
+    keys = ("recall_at_1", "recall_at_5", "recall_at_10")
+    return {"engine": rep["engine"], "reference": rep["reference_order"],
+            "equal_recall_at_1_5_10": all(rep["engine"][k] == rep["reference_order"][k] for k in keys),
+            "equal_subset_recalls": all(rep["engine"][k] == rep["reference_order"][k] for k in ("subset_recall_at_1", "subset_recall_at_2", "subset_recall_at_3")),
+            "top1_image_equal_pct": rep["top1_image_equal_pct"],
+            "top10_order_equal_pct": round(100.0 * float((o_ref == o_eng).all(1).float().mean()), 3),
+            "max_abs_dsim": rep["max_abs_dsim"], "rms_dsim": rep["rms_dsim"], "scores_over_1e-3": int(((s_eng - s_ref).abs() > 1e-3).sum()),
+            "scores": int(s_ref.numel()), "trunk_weights": "fp16-valued (a GPU-trained reference checkpoint: eva_vit.py:410-425)" if h16 else "fp32-valued synthetic"}

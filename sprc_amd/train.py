@@ -42,12 +42,15 @@ class _K:
         self._ws: Dict[str, torch.Tensor] = {}
         self._xt: Dict[int, tuple] = {}          # transposes of SAVED activations, per step: id(x) -> (x, x^T); holding x keeps its address its own
 
-    def transpose_saved(self, x):
-        """x^T of an activation the forward pass saved: the q / k / v linears of an attention (and both FFN halves of a row set) read the
-        same input, so its transpose is formed once per step.  Gradients (dy) are transient tensors and are not cached."""
+    def transpose_saved(self, x, last=False):
+        """x^T of a saved activation that SEVERAL linears read (the q / k / v projections of an attention): formed once, dropped by its
+        last consumer (`last`), so that at most one attention's inputs are held transposed at a time.  Inputs with one
+        consumer and gradients (dy) are transposed transiently."""
         hit = self._xt.get(id(x))
         if hit is None or hit[0] is not x:
             hit = self._xt[id(x)] = (x, self.transpose(x))
+        if last:
+            self._xt.pop(id(x), None)
         return hit[1]
 
     def empty(self, *shape):
@@ -141,11 +144,13 @@ class _Linear:
     def fwd(self, x, resid=None):
         return self.k.gemm(x, self.W, bias=self.b, resid=resid)
 
-    def bwd(self, x, dy, acc=None, need_dx=True):
-        """dW += dy^T x, db += colsum(dy); returns dx (+ acc: the running gradient of x from other paths) or None."""
+    def bwd(self, x, dy, acc=None, need_dx=True, shared=0):
+        """dW += dy^T x, db += colsum(dy); returns dx (+ acc: the running gradient of x from other paths) or None.
+        shared: x is read by several linears of this step (1: cache its transpose, 2: this is its last consumer)."""
         k = self.k
         assert self.W.shape[0] % 32 == 0 or not need_dx, "dX = dY . W reduces over the N output features: the fp32 GEMM needs N % 32 == 0"
-        k.gemm(k.transpose(dy), k.transpose_saved(x), resid=self.gW, out=self.gW)
+        xt = k.transpose_saved(x, last=shared == 2) if shared else k.transpose(x)
+        k.gemm(k.transpose(dy), xt, resid=self.gW, out=self.gW)
         if self.gb is not None:
             k.colsum(dy, self.gb)
         if not need_dx:
@@ -217,11 +222,12 @@ class TrainStep:
         dt = k.ln_bwd(c["t"], self.P[gn], dy, self.eps, self.G[gn], self.G[bn])
         dctx = self._lin(pre + "output.dense.weight").bwd(c["ctx"], dt if c["do"] is None else k.dropout(dt, c["do"]))
         dq, dk, dv = k.attention_bwd(c["q"], c["k"], c["v"], dctx, c["B"], self.H, c["Sq"], c["Sk"], c["mask"], self.sc, drop=c["dp"])
-        dxq = self._lin(pre + "self.query.weight").bwd(c["xq"], dq, acc=dt)          # residual path + query path
+        same = c["xq"] is c["xkv"]                                                  # self-attention: q / k / v read one input
+        dxq = self._lin(pre + "self.query.weight").bwd(c["xq"], dq, acc=dt, shared=1 if same else 0)          # residual path + query path
         tgt = dxq if c["same"] else dkv_acc
         need = tgt is not None
-        r = self._lin(pre + "self.key.weight").bwd(c["xkv"], dk, acc=tgt, need_dx=need)
-        r = self._lin(pre + "self.value.weight").bwd(c["xkv"], dv, acc=r if need else None, need_dx=need)
+        r = self._lin(pre + "self.key.weight").bwd(c["xkv"], dk, acc=tgt, need_dx=need, shared=1)
+        r = self._lin(pre + "self.value.weight").bwd(c["xkv"], dv, acc=r if need else None, need_dx=need, shared=2)
         return r if c["same"] else dxq
 
     def _ffn_fwd(self, pre_i, pre_o, x, do=None):

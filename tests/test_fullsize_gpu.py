@@ -194,3 +194,46 @@ def test_c5_shard_bf16_ranking_at_scale():
     assert torch.equal(bi, i) and torch.equal(bv, v)
     col = listed.to(DEV).clamp(min=0)
     assert torch.equal(bl, torch.where(listed.to(DEV) >= 0, sim.gather(1, col), torch.full_like(bl, float("-inf"))))
+
+
+def _c5_features(n, nq, seed=7, chunk=25_000):
+    """n x 32 x 256 unit-norm bf16 gallery features (generated in chunks: the fp32 draw of 1 M images would be 32 GB) + nq bf16 queries"""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    feats = torch.empty((n, 32, 256), dtype=torch.bfloat16, device=DEV)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        feats[s:s + m] = torch.nn.functional.normalize(torch.randn((m, 32, 256), generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    fusion = torch.nn.functional.normalize(torch.randn((nq, 256), generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    return feats, fusion
+
+
+def test_c5_full_size_ranking_one_gpu_eight_logical_shards():
+    """BASELINE.json config C5 AT ITS STATED SIZE: a 1 000 000-image gallery (32 x 256 bf16 = 16.4 GB: 18 x inside one
+    MI355X's 288 GB) x 10 000 queries, in 8 logical shards of 125 000 through ShardedRanker's query blocks and the k x 8 merge
+    (dist.rank_logical_shards: the 8-GPU data flow without the collectives): top-51 bit-identical to a GLOBAL pass over the whole gallery,
+    and -- on a sample of the queries -- to the numpy oracle's stable order of the device scores.  20.5 TFLOP of max-over-32 similarity."""
+    import time
+    from sprc_amd.dist import ShardedRanker, rank_logical_shards
+    N, nq, k = 1_000_000, 10_000, 51
+    feats, fusion = _c5_features(N, nq)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mv, mi = rank_logical_shards(feats, fusion, k, 8)
+    torch.cuda.synchronize()
+    t_sh = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    gv, gi = ShardedRanker(feats, 0, always_exchange=False).rank(fusion, k)             # global pass: blocks of 536 query rows x 1 M scores
+    torch.cuda.synchronize()
+    t_gl = time.perf_counter() - t0
+    assert mi.shape == (nq, k) and torch.equal(mi, gi) and torch.equal(mv, gv)
+    assert int(mi.min()) >= 0 and int(mi.max()) < N
+    rows = torch.arange(0, nq, 625, device=DEV)                                          # 16 queries through the oracle, on the device scores
+    sim = E.sim_max(fusion[rows].contiguous(), feats)
+    want_v, want_i = O.topk_stable(sim.cpu().numpy(), k)
+    np.testing.assert_array_equal(mi[rows].cpu().numpy(), want_i.astype(np.int32))
+    np.testing.assert_array_equal(mv[rows].cpu().numpy(), want_v)
+    cols = torch.arange(0, N, 40_009, device=DEV)
+    want = torch.einsum("qe,nje->qnj", fusion[rows].double(), feats[cols].double()).max(-1).values
+    np.testing.assert_allclose(sim[:, cols].cpu().numpy(), want.cpu().numpy(), atol=2e-3, rtol=0)
+    print(f"\n[C5 full size] 1 000 000 x 10 000, top-51: 8 logical shards {t_sh * 1e3:.0f} ms ({2 * 32 * 256 * N * nq / t_sh / 1e12:.0f} TFLOP/s incl. top-k and merge), "
+          f"global pass {t_gl * 1e3:.0f} ms; identical bits")
