@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPRC_ABI_VERSION 4
+#define SPRC_ABI_VERSION 5
 
 enum { SPRC_OK = 0, SPRC_EINVAL = -1, SPRC_ELAUNCH = -2, SPRC_EWORKSPACE = -3, SPRC_EUNSUPPORTED = -4 };
 enum { SPRC_F32 = 0, SPRC_BF16 = 1,
@@ -420,12 +420,17 @@ int sprc_align_mse(const float* h, int64_t sample_stride, int32_t Lq, int32_t D,
  * Training BACKWARD: the kernels sprc_amd/train.py sequences into the gradient of
  * Blip2QformerCirAlignPrompt.forward (align_prompt.py:95-200) for blip_fine_tune_2.py:293-304.  The ViT is frozen in the
  * reference (align_prompt.py:64-69): what trains is the Q-Former, ln_vision, the ITC heads, query / prompt tokens and temp.
- * All fp32.  Products run on sprc_gemm (exact-fp32 MFMA) through transposed operand copies: dX = dY . W as
- * sprc_gemm(A = dY, W = W^T), dW (+)= dY^T . X as sprc_gemm(A = dY^T, W = X^T, resid = dW).
+ * Products run on sprc_gemm through transposed operand copies: dX = dY . W as sprc_gemm(A = dY, W = W^T), dW (+)= dY^T . X as
+ * sprc_gemm(A = dY^T, W = X^T, resid = dW) -- on the exact-fp32 MFMA (the parity mode), or (ABI 5) on fp16 OPERAND COPIES with fp32
+ * accumulation, fp32 outputs and fp32 master weights: the reference's training arithmetic (fp16 autocast + GradScaler,
+ * blip_fine_tune_2.py:290-303).  Everything else (LayerNorm, GELU, softmax, losses, every gradient buffer) is fp32.
  * ---------------------------------------------------------------------------------------- */
 
 /* dst[c, r] = src[r, c]; leading dimensions in elements. */
 int sprc_transpose_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int32_t rows, int32_t cols, sprc_stream s);
+/* ABI 5: dst[c, r] = (dtype) src[r, c], dtype SPRC_F16 | SPRC_BF16: the transposed 16-bit operand copy of the 16-bit training products
+ * (replaces the x.t() / grad.t() views torch's autograd hands its fp16 matmuls under autocast; Qformer.py's nn.Linear backward). */
+int sprc_transpose_f32_to16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t rows, int32_t cols, int32_t dtype, sprc_stream s);
 /* out[n] (+)= sum_m x[m, n]  (bias gradients; fixed summation order). */
 int sprc_colsum_f32(const float* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, sprc_stream s);
 /* y = x Phi(x) (exact erf form, Qformer.py:482-490 ACT2FN["gelu"]) and dx = dy (Phi(x) + x phi(x)). */

@@ -380,13 +380,16 @@ def effective_drop_seed(dropout_seed: int, step: int = 1) -> int:
     return (dropout_seed * 0x9E3779B1 + step) & 0xFFFFFFFFFFFFFFFF
 
 
-def train_goldens(out: Path, seed: int = 4, dropout: bool = False):
+def train_goldens(out: Path, seed: int = 4, dropout: bool = False, autocast: bool = False):
     """Training forward + backward (N4): the REFERENCE's Blip2QformerCirAlignPrompt.forward (align_prompt.py:95-200) in eval mode on 5
     (reference, target, caption) triplets, depth-2 ViT-g + the full Q-Former: the three losses, and the gradient of
     loss_itc + 0.4 loss_rtc + 0.4 loss_align (blip_fine_tune_2.py:293-304) with respect to every trainable tensor, as
     `grad_functionals`; tensors the reference leaves without a gradient (itm_head, the LM head) are listed."""
     cfg = get_config("pretrain", vit_depth=2)
     sd = synth.make_state_dict(cfg, seed=seed)
+    # autocast=True: forward + backward under torch.autocast("cpu", float16) with the loss scaled by GradScaler's initial 2^16 and the
+    # gradients unscaled afterwards -- the reference's training ARITHMETIC (blip_fine_tune_2.py:290-303: `with torch.cuda.amp.autocast():`
+    # ... `scaler.scale(loss).backward()`), CPU autocast standing in for CUDA autocast (op lists and accumulation orders differ: a proxy).
     # dropout=True: the reference AS IT TRAINS (blip_fine_tune_2.py:290 `blip_model.train()`: Q-Former dropout p = 0.1 active, the ViT
     # pinned to eval by align_prompt.py:67-68) with the masks injected (`inject_dropout_masks`); False: eval mode
     model = ref_import.build_reference_model(cfg, sd, eval_mode=not dropout)
@@ -397,8 +400,10 @@ def train_goldens(out: Path, seed: int = 4, dropout: bool = False):
     if dropout:
         assert model.training and model.Qformer.training and not model.visual_encoder.training
         state = inject_dropout_masks(model, effective_drop_seed(DROPOUT_SEED), DROPOUT_P)
+    import contextlib
+    amp = (lambda: torch.autocast("cpu", dtype=torch.float16)) if autocast else contextlib.nullcontext
     model.tokenizer.set_next(ids, mask)
-    with torch.no_grad():
+    with torch.no_grad(), amp():
         out_d = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
     if state is not None:                                   # the second evaluation below must draw the same masks
         n_sites = len(state["calls"])
@@ -406,11 +411,24 @@ def train_goldens(out: Path, seed: int = 4, dropout: bool = False):
         state["pass"], state["calls"] = -1, []
     model.tokenizer.set_next(ids, mask)
     model.zero_grad()
-    losses = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
+    with amp():
+        losses = model({"image": images[:B], "target": images[B:], "text_input": ["caption"] * B})
+        total = sum(GRAD_WEIGHTS[k] * v for k, v in losses.items())
     if state is not None:
         assert all(abs(float(losses[k]) - float(out_d[k])) < 1e-6 for k in losses), "the injected masks are not reproducible"
-    total = sum(GRAD_WEIGHTS[k] * v for k, v in losses.items())
-    total.backward()
+    loss_scale = 65536.0 if autocast else 1.0
+    while True:                                             # GradScaler's rule (torch/amp/grad_scaler.py): a step whose gradients hold inf / nan is
+        model.zero_grad()                                   # skipped and the scale halved (backoff_factor 0.5) -- repeated until a step goes through
+        (total * loss_scale).backward(retain_graph=autocast)
+        finite = all(bool(torch.isfinite(p_.grad).all()) for p_ in model.parameters() if p_.grad is not None)
+        if finite or not autocast:
+            break
+        print(f"  loss scale {loss_scale:g}: non-finite gradients, halving (GradScaler backoff)")
+        loss_scale *= 0.5
+    if autocast:
+        for p_ in model.parameters():
+            if p_.grad is not None:
+                p_.grad.div_(loss_scale)
     grads, no_grad, frozen = {}, [], []
     for name, p_ in model.named_parameters():
         if not p_.requires_grad:
@@ -428,7 +446,7 @@ def train_goldens(out: Path, seed: int = 4, dropout: bool = False):
                         no_grad_names=np.array(no_grad), grad_weights=json.dumps(GRAD_WEIGHTS),
                         dropout_p=np.float64(DROPOUT_P if dropout else 0.0), dropout_seed=np.int64(DROPOUT_SEED if dropout else 0),
                         drop_seed_effective=np.uint64(effective_drop_seed(DROPOUT_SEED) if dropout else 0),
-                        dropout_sites=np.int64(n_sites if dropout else 0),
+                        dropout_sites=np.int64(n_sites if dropout else 0), autocast_fp16=np.int64(int(autocast)), loss_scale=np.float64(loss_scale),
                         **{k: np.float64(v.item()) for k, v in out_d.items()})
     print(f"wrote {out}:", {k: round(v.item(), 6) for k, v in out_d.items()}, f"{len(grads)} gradient tensors, no grad: {no_grad[:6]} ...")
 
@@ -492,6 +510,8 @@ def main():
         train_goldens(GOLD / "train_eva.npz")
     if want("train_dropout"):                   # the reference as it trains: Q-Former dropout p = 0.1 on, reproducible injected masks
         train_goldens(GOLD / "train_dropout_eva.npz", dropout=True)
+    if only is not None and "train_autocast" in only:   # (explicit only: ~10 min) the reference's training ARITHMETIC: fp16 autocast + loss scaling
+        train_goldens(GOLD / "train_autocast_eva.npz", autocast=True)
     if want("rerank"):
         rerank_goldens(GOLD / "rerank_eva.npz")
     if want("planted"):

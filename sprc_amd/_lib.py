@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("SPRC_LIB_PATH") or (Path(__file__).resolve().par
 
 SPRC_F16X3 = 4                                        # storage layout of split-precision activations: rows [hi fp16 | lo e4m3 | hi e4m3] (sprc.h)
 SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: IEEE half (compute dtype since ABI 3); FP8: OCP e4m3fn operands
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 FP8_ALL, FP8_MLP = 1, 2                               # sprc_vit_model.fp8: qkv + fc1 + fc2, or fc1 + fc2 only, on e4m3fn operands
 DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16, "fp16": SPRC_F16, "f16": SPRC_F16,
@@ -150,6 +150,7 @@ SIGNATURES = {
     "sprc_contrastive_ce": (i32, [vp, i64, i32, f32, vp, vp]),
     "sprc_align_mse": (i32, [vp, i64, i32, i32, vp, i32, vp, vp]),
     "sprc_transpose_f32": (i32, [vp, i64, vp, i64, i32, i32, vp]),
+    "sprc_transpose_f32_to16": (i32, [vp, i64, vp, i64, i32, i32, i32, vp]),
     "sprc_colsum_f32": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "sprc_gelu_fwd": (i32, [vp, vp, sz, vp]),
     "sprc_gelu_bwd": (i32, [vp, vp, vp, sz, vp]),

@@ -32,19 +32,53 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
     }
 }
 
-// out[n] (+)= sum_m x[m, n]: one workgroup per 64 columns, 4 waves stride the rows, fixed-order combine
+// out[n] (+)= sum_m x[m, n].  One workgroup per 32 columns (a 128-B line per row), 8 row lanes x 32 columns, every thread keeps 4 independent
+// partial sums over its rows (m = ty, ty + 8, ...), combined in a fixed order: deterministic.  (The first form -- one workgroup per 64 columns,
+// 4 waves striding ALL rows one load at a time -- ran 12 workgroups for N = 768: 128 us per call on average, 46 ms of a 257-ms training step,
+// profiles/r05_train_step_kernel_stats_before.csv.)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int64_t ld, int M, int N, float* out, int accumulate) {
-    __shared__ float part[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
-    float acc = 0.f;
-    if (n < N)
-        for (int m = wave; m < M; m += 4) acc += x[(int64_t)m * ld + n];
-    part[wave][lane] = acc;
+    __shared__ float part[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + tx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < N) {
+        const float* col = x + n;
+        int m = ty;
+        for (; m + 24 < M; m += 32) {
+            a0 += col[(int64_t)m * ld]; a1 += col[(int64_t)(m + 8) * ld]; a2 += col[(int64_t)(m + 16) * ld]; a3 += col[(int64_t)(m + 24) * ld];
+        }
+        for (; m < M; m += 8) a0 += col[(int64_t)m * ld];
+    }
+    part[ty][tx] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (wave == 0 && n < N) {
-        const float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    if (ty == 0 && n < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s += part[r][tx];
         out[n] = accumulate ? out[n] + s : s;
+    }
+}
+
+// dst[c, r] = (16-bit) src[r, c]: the transposed OPERAND COPY of the 16-bit training products (dW = dY^T . X reduces over the rows of dY and X)
+template <bool F16>
+__global__ __launch_bounds__(256) void transpose_f32_to16_kernel(const float* __restrict__ src, int64_t ld_src, uint16_t* __restrict__ dst,
+                                                                 int64_t ld_dst, int rows, int cols) {
+    __shared__ float tile[TR_TILE][TR_TILE + 1];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
+    const int r0 = blockIdx.y * TR_TILE, c0 = blockIdx.x * TR_TILE;
+#pragma unroll
+    for (int i = 0; i < TR_TILE; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        tile[ty + i][tx] = (r < rows && c < cols) ? src[(int64_t)r * ld_src + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TR_TILE; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (c < cols && r < rows) {
+            const float v = tile[tx][ty + i];
+            dst[(int64_t)c * ld_dst + r] = F16 ? __builtin_bit_cast(uint16_t, (_Float16)v) : f32_to_bf16_bits(v);
+        }
     }
 }
 
@@ -60,7 +94,7 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // ---- LayerNorm backward: one wave per row (the row in registers), D <= 2048 ----
-constexpr int LNB_MAXC = 8, LNB_ROWS = 4;
+constexpr int LNB_MAXC = 8, LNB_ROWS = 4, LNB_RPW = 8;      // 4 waves x 8 rows each per block: 32 rows share one partial record
 struct LnBwdParams {
     const float* x; int64_t ldx; const float* gamma; const float* dy; int64_t lddy; float eps; int M, D;
     float* dx; int64_t lddx; float* part;      // part: [blocks][2][D] per-block partial sums of (dy * xhat, dy)
@@ -68,12 +102,15 @@ struct LnBwdParams {
 __global__ __launch_bounds__(64 * LNB_ROWS) void layernorm_bwd_kernel(LnBwdParams p) {
     extern __shared__ float sh[];               // [LNB_ROWS][2][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * LNB_ROWS + wave;
     const int nch = p.D >> 2;
     float* mine = sh + (size_t)wave * 2 * p.D;
-    float4 xv[LNB_MAXC], gv[LNB_MAXC];
-    const bool live = row < p.M;
-    if (live) {
+    float4 pg[LNB_MAXC], pb[LNB_MAXC];          // this wave's running contributions to dgamma / dbeta over its LNB_RPW rows (row order)
+#pragma unroll
+    for (int c = 0; c < LNB_MAXC; ++c) pg[c] = pb[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < LNB_RPW; ++j) {
+        const int row = (blockIdx.x * LNB_ROWS + wave) * LNB_RPW + j;
+        if (row >= p.M) break;
+        float4 xv[LNB_MAXC], gv[LNB_MAXC];
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < LNB_MAXC; ++c) {
@@ -101,8 +138,8 @@ __global__ __launch_bounds__(64 * LNB_ROWS) void layernorm_bwd_kernel(LnBwdParam
                 xv[c].x = (xv[c].x - mean) * rstd; xv[c].y = (xv[c].y - mean) * rstd;
                 xv[c].z = (xv[c].z - mean) * rstd; xv[c].w = (xv[c].w - mean) * rstd;
                 // per-row contributions to dgamma / dbeta
-                reinterpret_cast<float4*>(mine)[i] = make_float4(gv[c].x * xv[c].x, gv[c].y * xv[c].y, gv[c].z * xv[c].z, gv[c].w * xv[c].w);
-                reinterpret_cast<float4*>(mine + p.D)[i] = gv[c];
+                pg[c].x += gv[c].x * xv[c].x; pg[c].y += gv[c].y * xv[c].y; pg[c].z += gv[c].z * xv[c].z; pg[c].w += gv[c].w * xv[c].w;
+                pb[c].x += gv[c].x; pb[c].y += gv[c].y; pb[c].z += gv[c].z; pb[c].w += gv[c].w;
                 gv[c].x *= gm.x; gv[c].y *= gm.y; gv[c].z *= gm.z; gv[c].w *= gm.w;
                 s1 += (gv[c].x + gv[c].y) + (gv[c].z + gv[c].w);
                 s2 += (gv[c].x * xv[c].x + gv[c].y * xv[c].y) + (gv[c].z * xv[c].z + gv[c].w * xv[c].w);
@@ -120,8 +157,14 @@ __global__ __launch_bounds__(64 * LNB_ROWS) void layernorm_bwd_kernel(LnBwdParam
                                     rstd * (gv[c].z - s1 - xv[c].z * s2), rstd * (gv[c].w - s1 - xv[c].w * s2));
             }
         }
-    } else {
-        for (int i = lane; i < 2 * p.D; i += 64) mine[i] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < LNB_MAXC; ++c) {
+        const int i = lane + c * 64;
+        if (i < nch) {
+            reinterpret_cast<float4*>(mine)[i] = pg[c];
+            reinterpret_cast<float4*>(mine + p.D)[i] = pb[c];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * p.D; i += 64 * LNB_ROWS) {
@@ -402,9 +445,20 @@ extern "C" int sprc_transpose_f32(const float* src, int64_t ld_src, float* dst, 
     return SPRC_OK;
 }
 
+extern "C" int sprc_transpose_f32_to16(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t rows, int32_t cols, int32_t dtype,
+                                       sprc_stream s) {
+    SPRC_REQUIRE(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "sprc_transpose_f32_to16: bad arguments");
+    SPRC_REQUIRE(is16(dtype), "sprc_transpose_f32_to16: dtype %d is not a 16-bit type", dtype);
+    const dim3 grid((cols + TR_TILE - 1) / TR_TILE, (rows + TR_TILE - 1) / TR_TILE);
+    if (dtype == SPRC_F16) hipLaunchKernelGGL(transpose_f32_to16_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, src, ld_src, (uint16_t*)dst, ld_dst, rows, cols);
+    else hipLaunchKernelGGL(transpose_f32_to16_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, src, ld_src, (uint16_t*)dst, ld_dst, rows, cols);
+    SPRC_CHECK_LAUNCH("sprc_transpose_f32_to16");
+    return SPRC_OK;
+}
+
 extern "C" int sprc_colsum_f32(const float* x, int64_t ld, int32_t M, int32_t N, float* out, int32_t accumulate, sprc_stream s) {
     SPRC_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "sprc_colsum_f32: bad arguments");
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)s, x, ld, M, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, (hipStream_t)s, x, ld, M, N, out, accumulate);
     SPRC_CHECK_LAUNCH("sprc_colsum_f32");
     return SPRC_OK;
 }
@@ -426,7 +480,7 @@ extern "C" int sprc_gelu_bwd(const float* x, const float* dy, float* dx, size_t 
 }
 
 extern "C" size_t sprc_layernorm_bwd_workspace_bytes(int32_t M, int32_t D) {
-    return (size_t)((M + LNB_ROWS - 1) / LNB_ROWS) * 2 * D * sizeof(float);
+    return (size_t)((M + LNB_ROWS * LNB_RPW - 1) / (LNB_ROWS * LNB_RPW)) * 2 * D * sizeof(float);
 }
 
 extern "C" int sprc_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t lddy, float eps, int32_t M,
@@ -435,7 +489,7 @@ extern "C" int sprc_layernorm_bwd(const float* x, int64_t ldx, const float* gamm
     SPRC_REQUIRE(D > 0 && D % 4 == 0 && D <= 64 * 4 * LNB_MAXC && ldx % 4 == 0 && lddy % 4 == 0 && (!dx || lddx % 4 == 0),
                  "sprc_layernorm_bwd: D=%d unsupported (D %% 4 == 0, D <= 2048, leading dimensions %% 4 == 0)", D);
     SPRC_REQUIRE(ws_bytes >= sprc_layernorm_bwd_workspace_bytes(M, D) && ((uintptr_t)ws % 16) == 0, "sprc_layernorm_bwd: workspace too small");
-    const int nblocks = (M + LNB_ROWS - 1) / LNB_ROWS;
+    const int nblocks = (M + LNB_ROWS * LNB_RPW - 1) / (LNB_ROWS * LNB_RPW);
     LnBwdParams p{x, ldx, gamma, dy, lddy, eps, M, D, dx, lddx, (float*)ws};
     const size_t lds = (size_t)LNB_ROWS * 2 * D * sizeof(float);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblocks), dim3(64 * LNB_ROWS), lds, (hipStream_t)s, p);

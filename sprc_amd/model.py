@@ -66,7 +66,8 @@ class Blip2QformerCirAlignPrompt(nn.Module):
     PRETRAINED_MODEL_CONFIG_DICT = {k: k for k in MODEL_TYPES}     # align_prompt.py:38-42 ("coco" has no CIR use)
 
     def __init__(self, model_type: str = "pretrain", compute_dtype: str = "fp16", rank_dtype: str = "fp32",
-                 cfg: Optional[SprcConfig] = None, max_batch: int = 128, tokenizer=None, device="cpu", train_vit_dtype: str = "fp32"):
+                 cfg: Optional[SprcConfig] = None, max_batch: int = 128, tokenizer=None, device="cpu", train_vit_dtype: str = "fp32",
+                 train_products: str = "fp32"):
         """train_vit_dtype: dtype of the FROZEN ViT trunk inside a training step -- "fp32" (gradients within 1e-4 of the reference's fp32
         graph) or "fp16" (what the reference's loop does: the trunk runs under `torch.cuda.amp.autocast`, blip_fine_tune_2.py:293; 64
         ViT-g images per step then cost 45 ms instead of 500).  The Q-Former's forward and backward are fp32 either way."""
@@ -76,6 +77,11 @@ class Blip2QformerCirAlignPrompt(nn.Module):
         if train_vit_dtype not in ("fp32", "fp16"):
             raise ValueError(f"train_vit_dtype {train_vit_dtype!r}")
         self.train_vit_dtype = train_vit_dtype
+        # train_products: the products of the TRAINABLE part of a training step -- "fp32" (exact-fp32 MFMA: the parity mode) or "fp16"
+        # (fp16 operand copies, fp32 accumulate / outputs / master weights: the reference's autocast arithmetic, ~2.3 x faster per step)
+        if train_products not in ("fp32", "fp16"):
+            raise ValueError(f"train_products {train_products!r}")
+        self.train_products = train_products
         self.max_txt_len = self.cfg.max_txt_len
         for name, shape, _ in synth.param_specs(self.cfg):
             _register(self, name, shape, device)
@@ -267,7 +273,8 @@ class _TrainFn(torch.autograd.Function):
         drop_p = model.dropout_p if model.training else 0.0
         model._drop_step += 1
         seed = (int(model.dropout_seed) * 0x9E3779B1 + model._drop_step) & 0xFFFFFFFFFFFFFFFF
-        step = TrainStep(model.cfg, {n: t.float().contiguous() for n, t in P.items()}, model._train_engine(), dropout_p=drop_p, seed=seed)
+        step = TrainStep(model.cfg, {n: t.float().contiguous() for n, t in P.items()}, model._train_engine(), dropout_p=drop_p, seed=seed,
+                         products=model.train_products)
         losses = step.forward(image.to(model.device), target.to(model.device), input_ids, attention_mask)
         ctx.step, ctx.names = step, names
         return losses["loss_itc"].clone(), losses["loss_rtc"].clone(), losses["loss_align"].clone()

@@ -36,9 +36,11 @@ def _st():
 class _K:
     """fp32 kernel wrappers (one C call each)."""
 
-    def __init__(self, device):
+    def __init__(self, device, half: bool = False):
         self.lib = L.load()
         self.dev = device
+        self.half = bool(half)                   # products on fp16 OPERAND COPIES (fp32 accumulate / outputs): the reference's autocast arithmetic
+        self._c16: List[tuple] = []              # the last few fp16 operand copies (x, x16): q / k / v projections read one input back to back
         self._ws: Dict[str, torch.Tensor] = {}
         self._xt: Dict[int, tuple] = {}          # transposes of SAVED activations, per step: id(x) -> (x, x^T); holding x keeps its address its own
 
@@ -65,13 +67,34 @@ class _K:
             w = self._ws[key] = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.dev)
         return w
 
-    # y = x . W^T (+ bias) (+ resid); `out` may alias `resid`
+    def op16(self, x):
+        """fp16 operand copy of an fp32 [R, K] tensor (sprc_cast_f32_to_16); fp16 inputs pass through"""
+        if x.dtype == torch.float16:
+            return x
+        for src, c in self._c16:
+            if src is x:
+                return c
+        assert x.is_contiguous()
+        c = torch.empty(x.shape, dtype=torch.float16, device=self.dev)
+        L.check(self.lib.sprc_cast_f32_to_16(x.data_ptr(), c.data_ptr(), x.numel(), L.SPRC_F16, _st()), "sprc_cast_f32_to_16")
+        self._c16 = (self._c16 + [(x, c)])[-3:]
+        return c
+
+    # y = x . W^T (+ bias) (+ resid), fp32 out; `out` may alias `resid`.  half: the product runs on fp16 copies of x and W
     def gemm(self, x, W, bias=None, resid=None, out=None):
+        if self.half:
+            x, W = self.op16(x), self.op16(W)
         return E.gemm(x, W, bias=bias, resid=resid, out_dtype=F32, out=out)
 
     def transpose(self, x, pad=32):
-        """[rows, cols] -> [cols, rows padded to a multiple of `pad` with zeros] (a GEMM operand: the reduction runs over rows)."""
+        """[rows, cols] -> [cols, rows padded to a multiple of `pad` with zeros] (a GEMM operand: the reduction runs over rows);
+        half: an fp16 operand copy (rows padded to 64: the 16-bit kernels' K-tile)."""
         rows, cols = x.shape
+        if self.half:
+            rp = (rows + 63) // 64 * 64
+            out = (torch.zeros if rp != rows else torch.empty)((cols, rp), dtype=torch.float16, device=self.dev)
+            L.check(self.lib.sprc_transpose_f32_to16(x.data_ptr(), x.stride(0), out.data_ptr(), rp, rows, cols, L.SPRC_F16, _st()), "sprc_transpose_f32_to16")
+            return out
         rp = (rows + pad - 1) // pad * pad
         out = self.zeros(cols, rp) if rp != rows else self.empty(cols, rp)
         L.check(self.lib.sprc_transpose_f32(x.data_ptr(), x.stride(0), out.data_ptr(), rp, rows, cols, _st()), "sprc_transpose_f32")
@@ -140,9 +163,16 @@ class _Linear:
         self.k, self.W, self.b = k, P[wname], (P[bname] if bname else None)
         self.gW, self.gb = G[wname], (G[bname] if bname else None)
         self._Wt = None
+        self._W16 = None                         # half mode: the step's fp16 copy of the fp32 master weight
 
     def fwd(self, x, resid=None):
-        return self.k.gemm(x, self.W, bias=self.b, resid=resid)
+        W = self.W
+        if self.k.half:
+            if self._W16 is None:
+                self._W16 = torch.empty(W.shape, dtype=torch.float16, device=W.device)
+                L.check(self.k.lib.sprc_cast_f32_to_16(W.data_ptr(), self._W16.data_ptr(), W.numel(), L.SPRC_F16, _st()), "sprc_cast_f32_to_16")
+            W = self._W16
+        return self.k.gemm(x, W, bias=self.b, resid=resid)
 
     def bwd(self, x, dy, acc=None, need_dx=True, shared=0):
         """dW += dy^T x, db += colsum(dy); returns dx (+ acc: the running gradient of x from other paths) or None.
@@ -166,7 +196,13 @@ DROP_SELF_P, DROP_SELF_OUT, DROP_CROSS_P, DROP_CROSS_OUT, DROP_FFN_Q, DROP_FFN_T
 
 
 class TrainStep:
-    def __init__(self, cfg, params: Dict[str, torch.Tensor], engine: E.Engine, dropout_p: float = 0.0, seed: int = 0):
+    def __init__(self, cfg, params: Dict[str, torch.Tensor], engine: E.Engine, dropout_p: float = 0.0, seed: int = 0, products: str = "fp32"):
+        """products: "fp32" -- every product of the trainable part on the exact-fp32 MFMA (the parity mode: gradients within 1.5e-5 of the
+        reference's fp32 forward + backward); "fp16" -- on fp16 operand copies with fp32 accumulation, fp32 outputs and fp32 master weights:
+        the reference's training arithmetic (blip_fine_tune_2.py:290-303: fp16 autocast under GradScaler; here only the OPERANDS are rounded,
+        the reference also rounds every linear's output).  Gradients of very small magnitude need the GradScaler's loss scale, as there."""
+        if products not in ("fp32", "fp16"):
+            raise ValueError(f"TrainStep products {products!r}")
         # `engine` runs the FROZEN ViT trunk only (vit_forward + its pre-ln_vision stream): fp32, or fp16 as under the reference's autocast
         # (blip_fine_tune_2.py:293); everything that trains -- ln_vision, the Q-Former, the heads -- is computed here on the exact-fp32 GEMM
         if engine.dt not in (L.SPRC_F32, L.SPRC_F16) or engine.fp8:
@@ -176,7 +212,7 @@ class TrainStep:
             raise ValueError("dropout_p must be in [0, 1)")
         self.drop_p, self.seed = float(dropout_p), int(seed) & 0xFFFFFFFFFFFFFFFF
         self.dev = engine.device
-        self.k = _K(self.dev)
+        self.k = _K(self.dev, half=products == "fp16")
         q = cfg.qformer
         self.Hd, self.H, self.Lq, self.Lt, self.eps = q.hidden, q.heads, q.num_query, cfg.max_txt_len, q.ln_eps
         self.sc = 1.0 / (q.head_dim ** 0.5)

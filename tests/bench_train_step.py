@@ -3,7 +3,7 @@
 cpu_baseline may import.)  One training step of the reference's loop (blip_fine_tune_2.py:281-304: forward of the three losses, `scaler.scale(loss).backward()`,
 AdamW) on the HIP training path (sprc_amd/train.py: fp32 kernels, full-depth frozen ViT + trainable Q-Former / heads / ln_vision),
 timed on the GPU, next to the same step of the CPU oracle (torch autograd over oracle.training_losses) on a smaller batch.
-    python tests/bench_train_step.py [batch=32] [steps=5] [cpu_batch=4] [fp32|fp16 trunk]
+    python tests/bench_train_step.py [batch=32] [steps=5] [cpu_batch=4] [fp32|fp16 trunk] [fp32|fp16 products]
 SURVEY.md section 8(f) N4: measurement of the training row (not the headline metric)."""
 import sys
 import time
@@ -23,6 +23,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 CPU_B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 VIT_DT = sys.argv[4] if len(sys.argv) > 4 else "fp32"          # dtype of the frozen trunk inside the step: fp32 | fp16 (the reference's autocast)
+PROD = sys.argv[5] if len(sys.argv) > 5 else "fp32"            # products of the trainable part: fp32 (parity mode) | fp16 (operand copies: autocast arithmetic)
 
 
 class _Tok:
@@ -37,7 +38,7 @@ cfg = get_config("pretrain")
 sd = synth.make_state_dict(cfg, seed=0)
 ids, mask, _ = synth.make_queries(B, B, seed=1)
 images = synth.make_images(2 * B, seed=0)
-model = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=B, train_vit_dtype=VIT_DT)
+model = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=B, train_vit_dtype=VIT_DT, train_products=PROD)
 model.load_state_dict(sd, strict=False)
 model = model.to(DEV)
 model.tokenizer = _Tok(ids, mask)
@@ -65,7 +66,7 @@ hist += [step() for _ in range(STEPS)]
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / STEPS
 # 2 B images through the frozen ViT (forward only) + four Q-Former passes forward and backward
-print(f"[train step, HIP path: {VIT_DT} frozen trunk, fp32 Q-Former forward + backward] batch {B} (2 x {B} images through ViT-g): {dt * 1e3:.0f} ms per step = {B / dt:.1f} triplets/s; "
+print(f"[train step, HIP path: {VIT_DT} frozen trunk, {PROD} products in the Q-Former's forward + backward] batch {B} (2 x {B} images through ViT-g): {dt * 1e3:.0f} ms per step = {B / dt:.1f} triplets/s; "
       f"loss {hist[0]:.4f} -> {hist[-1]:.4f} over {len(hist)} AdamW steps")
 
 if CPU_B > 0:

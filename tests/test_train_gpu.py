@@ -317,3 +317,56 @@ def test_backward_kernels_against_torch_autograd():
     hd, pd = h.to(DEV), prompt.to(DEV)
     L.check(lib.sprc_align_mse_bwd(hd.data_ptr(), 64 * 768, 32, 768, pd.data_ptr(), 4, 0.4, dh.data_ptr(), 64 * 768, st))
     torch.testing.assert_close(dh.cpu().double(), hh.grad, atol=1e-8, rtol=1e-4)
+
+
+def test_fp16_products_training_step_against_the_references_autocast_gradients(golden_dir):
+    """the training step in the REFERENCE'S ARITHMETIC.  blip_fine_tune_2.py:290-303 runs forward + backward under fp16
+    autocast with a GradScaler; `train_products="fp16"` runs every product of the trainable part on fp16 operand copies (fp32 accumulation,
+    fp32 outputs, fp32 master weights) and the frozen trunk on the fp16 engine.  Golden: the unmodified reference under
+    torch.autocast("cpu", float16) with GradScaler's backoff rule (tests/golden/train_autocast_eva.npz: its scale settled at 2^13 -- 2^16 .. 2^14
+    overflow the reference's fp16 gradients; CPU autocast stands in for CUDA autocast).  Two yardsticks, both as functional errors relative
+    to each tensor's gradient norm: the reference's autocast gradients are themselves up to 7.1e-2 (median 1.1e-2) from its fp32 gradients;
+    the engine, which rounds operands only, must sit CLOSER to the fp32 gradients than that, and within the autocast path's own distance of
+    the autocast gradients."""
+    import json
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    from test_oracle_golden import _grad_functionals
+    g32 = np.load(golden_dir / "train_eva.npz", allow_pickle=False)
+    g16 = np.load(golden_dir / "train_autocast_eva.npz", allow_pickle=False)
+    assert int(g16["autocast_fp16"]) == 1 and [str(n) for n in g16["grad_names"]] == [str(n) for n in g32["grad_names"]]
+    cfg = get_config(str(g32["model_type"]), vit_depth=int(g32["vit_depth"]))
+    sd = synth.make_state_dict(cfg, seed=int(g32["seed"]))
+    B = int(g32["batch"])
+    model = Blip2QformerCirAlignPrompt(cfg=cfg, compute_dtype="fp32", max_batch=8, train_vit_dtype="fp16", train_products="fp16")
+    assert not model.load_state_dict(sd, strict=False).missing_keys
+    model = model.to(DEV).eval()
+    model.tokenizer = _Tok(torch.from_numpy(g32["input_ids"]), torch.from_numpy(g32["attention_mask"]))
+    images = synth.make_images(2 * B, seed=int(g32["seed"]))
+    batch = {"image": images[:B].to(DEV), "target": images[B:].to(DEV), "text_input": ["caption"] * B}
+    w = json.loads(str(g32["grad_weights"]))
+    scale = float(g16["loss_scale"])
+    losses = model(batch)
+    (sum(w[k] * v for k, v in losses.items()) * scale).backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad / scale for n, p in model.named_parameters() if p.grad is not None}
+    assert all(bool(torch.isfinite(v).all()) for v in grads.values()) and len(grads) == len(g32["grad_names"])
+    for k in losses:
+        assert float(losses[k]) == pytest.approx(float(g32[k]), abs=2e-3), k
+
+    def worst_against(g):               # every error relative to the FP32 gradient norm; the key biases (mathematically zero gradients) are skipped
+        errs = []
+        for name, want, base in zip([str(n) for n in g["grad_names"]], g["grad_values"], g32["grad_values"]):
+            if base[0] < 1e-8:
+                continue
+            got = _grad_functionals(name, grads[name])
+            errs.append(float(np.abs(got[:3] - want[:3]).max() / base[0]))
+        return max(errs), float(np.median(errs))
+    w32, m32 = worst_against(g32)
+    w16, m16 = worst_against(g16)
+    ref = [float(np.abs(a[:3] - b[:3]).max() / a[0]) for a, b in zip(g32["grad_values"], g16["grad_values"]) if a[0] >= 1e-8]
+    print(f"\n[train step, fp16 products] functional error / ||g||: vs the reference's fp32 gradients worst {w32:.2e} median {m32:.2e}; vs its autocast "
+          f"gradients worst {w16:.2e} median {m16:.2e}; the reference's autocast vs its own fp32: worst {max(ref):.2e} median {float(np.median(ref)):.2e}")
+    assert w32 < max(ref) and m32 < float(np.median(ref))
+    assert w16 < 1.5 * max(ref)
