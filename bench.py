@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--qf-streams", type=int, default=2, help="2 = the gallery-side and the query-side Q-Former passes of a step run on two streams")
     ap.add_argument("--pipeline", type=int, default=1, help="1 = batch i's Q-Former passes and ranking overlap batch i+1's ViT (side streams, raw embeddings "
                     "double-buffered); instrumented steps (--prof-every) stay serialised")
+    ap.add_argument("--qf-group", type=int, default=1, help="G: the Q-Former stage (gallery-side pass, query fusion, ranking) of G consecutive steps runs once, "
+                    "on their G x 128 images and G x 233 queries; the ViT still runs per step on batches of 128 (1 = every step on its own)")
     ap.add_argument("--no-recall", action="store_true", help="skip the `recall` object (default ON at N = 1: after the timed region, Recall@1/5/10/50 + subset "
                     "recalls of the benchmarked engine on the planted-structure CIRR-val-sized case next to the UNMODIFIED REFERENCE's own scores for "
                     "every 22nd query of that case -- 191 queries x 2297 images, tests/golden/planted_c2_subset_eva*.npz; ~40 s; synthetic weights: "
@@ -336,10 +338,10 @@ def main():
         amax = cal.calibrate_fp8(images)
         del cal
         torch.cuda.empty_cache()
-        eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=max(BATCH, Q_PER_STEP), fp8_amax=amax, fp8_margin=1.1,
+        eng = E.Engine(cfg, sd, dev, dtype="fp8", max_batch=max(1, a.qf_group) * max(BATCH, Q_PER_STEP), fp8_amax=amax, fp8_margin=1.1,
                        fp8_base=a.fp8_base, fp8_layers=a.fp8_layers)
     else:
-        eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=max(BATCH, Q_PER_STEP),
+        eng = E.Engine(cfg, sd, dev, dtype=a.dtype, max_batch=max(1, a.qf_group) * max(BATCH, Q_PER_STEP),
                        qformer_x3=(0 if os.environ.get("SPRC_X3_OFF") else None))       # SPRC_X3_OFF=1: A/B line without the split-precision Q-Former
     del sd
     torch.cuda.empty_cache()
@@ -353,86 +355,119 @@ def main():
     assert (lo_g, hi_g) == (rank * GALLERY, (rank + 1) * GALLERY)
     assert bool((owner_of(lo_g + ref_slot.cpu(), world * GALLERY, world) == rank).all())
     ranker = ShardedRanker(gallery, index_base=lo_g)
-    raw = torch.empty((BATCH, cfg.vit.tokens, cfg.vit.width), dtype=torch.float32, device=dev)
+    # --qf-group G: the ViT runs on every step's batch of 128 images; the Q-Former stage (gallery-side pass, query fusion, ranking) of G
+    # consecutive steps runs ONCE, on the G x 128 images / G x 233 queries of those steps.  The Q-Former's products are small at one
+    # step's size (233 queries = 14 912 rows: 177 tiles of 256 x 256 on 256 CUs, 128 images = 4 096 rows: latency-bound launches); at
+    # G = 4 the same launches fill 91 % of their rounds (tools/qf_group_probe.py: image pass 4.96 -> 3.61 ms per 128 images, fusion
+    # 15.8 -> 14.0 ms per 233 queries).  Every step's work is done inside the timed region (a last partial group is flushed before the
+    # closing barrier); G = 1 is the step-by-step schedule of rounds 1-4.
+    G = max(1, a.qf_group)
+    NQG = G * Q_PER_STEP
+    ids_g, mask_g = ids.repeat(G, 1), mask.repeat(G, 1)
+    ref_slot_g = torch.cat([j * BATCH + ref_slot for j in range(G)])             # step j of a group draws its references from its own batch
 
-    # The gallery-side Q-Former pass (128 x 32 rows: small, latency-bound launches that leave most CUs idle) and the query-side fusion
+    # The gallery-side Q-Former pass (small, latency-bound launches that leave most CUs idle) and the query-side fusion
     # passes are independent until the ranking: they run on two streams (--qf-streams 1 serialises them for A/B runs).
     side = torch.cuda.Stream(device=dev) if a.qf_streams >= 2 else None
     main = torch.cuda.current_stream(dev)
-    # --pipeline 1: the Q-Former passes + ranking of batch i run on side streams WHILE the ViT of batch i+1 runs on the main stream (raw
+    # --pipeline 1: the Q-Former passes + ranking of group g run on side streams WHILE the ViT of group g+1 runs on the main stream (raw
     # embeddings double-buffered): the ViT's GEMMs own every CU while they run, but their partial last rounds, the small remainder
-    # launches and the bandwidth-bound LayerNorms leave CUs idle that the Q-Former's small launches can take.  Steps whose launches
+    # launches and the bandwidth-bound LayerNorms leave CUs idle that the Q-Former's launches can take.  Groups whose launches
     # are timed with HIP events (--prof-every) run on ONE stream, so per-kernel durations stay those of a kernel that has the chip
     # (and agree with a `rocprofv3 --kernel-trace` of `--pipeline 0 --qf-streams 1`, profiles/).
     pipe = a.pipeline and side is not None
     s_img, s_fuse = (side, torch.cuda.Stream(device=dev)) if pipe else (None, None)
-    raws = [raw, torch.empty_like(raw)] if pipe else [raw]
-    done = [torch.cuda.Event(), torch.cuda.Event()] if pipe else None
+    vit_streams = [main]           # (two ViT batches in flight on two streams, half a pass apart, were measured: 89.7 -> 90.3 ms per step -- DESIGN.md 5.4)
+    NBUF = 2 if pipe else 1
+    raws = torch.empty((NBUF, G * BATCH, cfg.vit.tokens, cfg.vit.width), dtype=torch.float32, device=dev)
+    done = [torch.cuda.Event() for _ in range(NBUF)] if pipe else None
+    groups = [0]                                                                  # groups run so far: the parity of the raw buffers
 
-    def step_pipelined(i: int):
-        buf = raws[i % 2]
-        main.wait_event(done[i % 2])                                              # batch i-2's Q-Former passes have read this buffer
-        eng.vit_forward(images, out=buf)
-        lo = (i * BATCH) % (GALLERY - BATCH)
-        s_img.wait_stream(main)
-        s_fuse.wait_stream(main)
-        s_img.wait_event(done[(i - 1) % 2])                                       # batch i-1's ranking has read the whole gallery: the slice
-        with torch.cuda.stream(s_img):                                            # copy below must not land under it
+    def qformer_stage(buf, first: int, n: int, serial: bool):
+        """gallery-side pass for the n x 128 images in buf, fusion of their n x 233 queries, ranking (on the current stream(s))"""
+        nq = n * Q_PER_STEP
+        refs = buf.index_select(0, ref_slot_g[:nq])                               # references come from the group's raw embeddings
+
+        def image_side():
+            feats, _ = eng.qformer_image(buf)                                     # R5(i) + vision_proj
+            for j in range(n):                                                    # resident gallery slices of these batches
+                lo = ((first + j) * BATCH) % (GALLERY - BATCH)
+                gallery[lo:lo + BATCH].copy_(feats[j * BATCH:(j + 1) * BATCH])
+            return feats
+        if side is not None and not serial:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                image_side().record_stream(side)
+            fusion, _ = eng.qformer_fuse(refs, ids_g[:nq], mask_g[:nq])           # R6 fusion half
+            main.wait_stream(side)
+        else:
+            image_side()
+            fusion, _ = eng.qformer_fuse(refs, ids_g[:nq], mask_g[:nq])
+        return ranker.rank(fusion, TOPK)                                          # R6 similarity + R7 top-k (+ exchanges)
+
+    def group_pipelined(first: int, n: int):
+        g = groups[0]
+        groups[0] += 1
+        buf = raws[g % NBUF][:n * BATCH]
+        vst = vit_streams[g % len(vit_streams)]
+        vst.wait_event(done[g % NBUF])                                            # group g-NBUF's Q-Former passes have read this buffer
+        with torch.cuda.stream(vst):
+            for j in range(n):
+                eng.vit_forward(images, out=buf[j * BATCH:(j + 1) * BATCH], slot=g % len(vit_streams))     # R3/R4
+        s_img.wait_stream(vst)
+        s_fuse.wait_stream(vst)
+        s_img.wait_event(done[(g - 1) % NBUF])                                    # group g-1's ranking has read the whole gallery: the slice
+        nq = n * Q_PER_STEP                                                       # copies below must not land under it
+        with torch.cuda.stream(s_img):
             feats, _ = eng.qformer_image(buf)
-            gallery[lo:lo + BATCH].copy_(feats)
+            for j in range(n):
+                lo = ((first + j) * BATCH) % (GALLERY - BATCH)
+                gallery[lo:lo + BATCH].copy_(feats[j * BATCH:(j + 1) * BATCH])
         with torch.cuda.stream(s_fuse):
-            fusion, _ = eng.qformer_fuse(buf.index_select(0, ref_slot), ids, mask)
-            s_fuse.wait_stream(s_img)                                             # the ranking reads the gallery slice of this batch
+            fusion, _ = eng.qformer_fuse(buf.index_select(0, ref_slot_g[:nq]), ids_g[:nq], mask_g[:nq])
+            s_fuse.wait_stream(s_img)                                             # the ranking reads the gallery slices of this group
             out = ranker.rank(fusion, TOPK)
-            done[i % 2].record(s_fuse)
+            done[g % NBUF].record(s_fuse)
         return out
 
     def drain():
         if pipe:
+            for st in vit_streams[1:]:
+                main.wait_stream(st)
             main.wait_stream(s_img)
             main.wait_stream(s_fuse)
 
-    def step(i: int, serial: bool = False):
-        eng.vit_forward(images, out=raw)                                          # R3/R4
-        lo = (i * BATCH) % (GALLERY - BATCH)
-        if side is not None and not serial:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                feats, _ = eng.qformer_image(raw)                                 # R5(i) + vision_proj
-                gallery[lo:lo + BATCH].copy_(feats)                               # resident gallery slice of this batch
-                feats.record_stream(side)
-            fusion, _ = eng.qformer_fuse(raw.index_select(0, ref_slot), ids, mask)    # R6 fusion half
-            main.wait_stream(side)
-        else:
-            feats, _ = eng.qformer_image(raw)
-            gallery[lo:lo + BATCH].copy_(feats)
-            fusion, _ = eng.qformer_fuse(raw.index_select(0, ref_slot), ids, mask)
-        return ranker.rank(fusion, TOPK)                                          # R6 similarity + R7 top-k (+ exchanges)
+    def group(first: int, n: int, serial: bool = False):
+        buf = raws[0][:n * BATCH]
+        for j in range(n):
+            eng.vit_forward(images, out=buf[j * BATCH:(j + 1) * BATCH])
+        return qformer_stage(buf, first, n, serial)
 
     def barrier():
         if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        (step_pipelined if pipe else step)(i)
+    for i in range(0, a.warmup, G):
+        (group_pipelined if pipe else group)(i, min(G, a.warmup - i))
     drain()
     barrier()
     # Per-launch HIP events cost two stream markers per launch (~7 us of pipeline bubble: 4.5 ms on a 100-ms step when every
-    # launch is recorded), so they are recorded on every `prof_every`-th step of the timed region only; `value` is the
-    # throughput of the WHOLE region, instrumented steps included.
+    # launch is recorded), so they are recorded on part of the timed region only -- G = 1: every `prof_every`-th step, G > 1: the
+    # first group; `value` is the throughput of the WHOLE region, instrumented steps included.
     n_prof = 0
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        rec = a.prof_every > 0 and i % a.prof_every == 0
+    for i in range(0, a.steps, G):
+        n = min(G, a.steps - i)
+        rec = a.prof_every > 0 and (i % a.prof_every == 0 if G == 1 else i == 0)
         if rec:
             drain()
             lib.sprc_prof_enable(1 if n_prof == 0 else 2)
-            n_prof += 1
-            step(a.warmup + i, serial=True)                                       # instrumented steps: ONE stream (see `pipe`)
+            n_prof += n                                                           # instrumented STEPS
+            group(a.warmup + i, n, serial=True)                                   # instrumented groups: ONE stream (see `pipe`)
             lib.sprc_prof_enable(0)
         else:
-            (step_pipelined if pipe else step)(a.warmup + i)
+            (group_pipelined if pipe else group)(a.warmup + i, n)
     drain()
     barrier()
     dt = time.perf_counter() - t0
@@ -494,7 +529,7 @@ def main():
                                    f"{'ViT-g' if a.backbone == 'pretrain' else 'ViT-L'} {a.dtype}, batch {BATCH}; step = encode {BATCH} images + "
                                    f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
-                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_streams": a.qf_streams, "pipeline": int(bool(a.pipeline)),
+                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_group": a.qf_group, "qformer_streams": a.qf_streams, "pipeline": int(bool(a.pipeline)),
                        "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if use_dist and backend == "nccl" else None),
                        "per_rank_ms_per_step": per_rank_ms,
                        "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if use_dist else None},

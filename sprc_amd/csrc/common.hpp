@@ -98,6 +98,19 @@ __device__ __forceinline__ void store_split4(char* row, int K, int col, float a,
     *reinterpret_cast<uint32_t*>(row + 2 * K + col) = pack_fp8x4(r0 * SPLIT_LO_SCALE, r1 * SPLIT_LO_SCALE, r2 * SPLIT_LO_SCALE, r3 * SPLIT_LO_SCALE);
     *reinterpret_cast<uint32_t*>(row + 3 * K + col) = pack_fp8x4(a, b, c, d);
 }
+// eight consecutive columns [col, col + 8) of a split row; col % 8 == 0, K % 8 == 0: 16 B of hi + 8 B + 8 B of e4m3
+__device__ __forceinline__ void store_split8(char* row, int K, int col, const f32x4& a, const f32x4& b) {
+    _Float16 h[8];
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { split_f16_res(a[e], h[e], r[e]); split_f16_res(b[e], h[4 + e], r[4 + e]); }
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    auto pk = [&](int i) { const h2 v = {h[i], h[i + 1]}; return __builtin_bit_cast(uint32_t, v); };
+    *reinterpret_cast<u32x4*>(row + 2 * col) = u32x4{pk(0), pk(2), pk(4), pk(6)};
+    *reinterpret_cast<u32x2*>(row + 2 * K + col) = u32x2{pack_fp8x4(r[0] * SPLIT_LO_SCALE, r[1] * SPLIT_LO_SCALE, r[2] * SPLIT_LO_SCALE, r[3] * SPLIT_LO_SCALE),
+                                                          pack_fp8x4(r[4] * SPLIT_LO_SCALE, r[5] * SPLIT_LO_SCALE, r[6] * SPLIT_LO_SCALE, r[7] * SPLIT_LO_SCALE)};
+    *reinterpret_cast<u32x2*>(row + 3 * K + col) = u32x2{pack_fp8x4(a[0], a[1], a[2], a[3]), pack_fp8x4(b[0], b[1], b[2], b[3])};
+}
 __device__ __forceinline__ void store_split1(char* row, int K, int col, float x) {
     _Float16 h;
     float r;

@@ -73,6 +73,8 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
     p.debug = dbg;
     p.duo_sleep = 0; p.duo_ctr = nullptr;
+    static const int epi_wide = env_int("SPRC_EPI_WIDE", 1);       // 0: 4 columns per lane in every epilogue (A/B switch, gemm_epilogue)
+    p.epi_wide = epi_wide;
     p.order = -1;                       // per-kernel default (launch_*), SPRC_GEMM_ORDER overrides
     p.k8 = a->k8;
     hipStream_t st = (hipStream_t)s;

@@ -60,6 +60,7 @@ struct GemmParams {
                                         // every row of A and W (K-tiles of 128 bytes either way); their partial sum enters scaled by 2^-18
     int duo_sleep;                      // duo kernel (gemm_duo.hpp): cycles the second workgroup of a CU sleeps before its first tile (0: no stagger)
     int* duo_ctr;                       // duo kernel: per-CU arrival counters (DUO_CTRS ints, only ever incremented)
+    int epi_wide;                       // 1: 8 columns per lane in the epilogues of outputs narrower than fp32 (16-B stores); 0: 4 (A/B switch)
 };
 
 // MX block scales of the split-precision products' e4m3 segments: E8M0 118 = 2^-9 on BOTH operands -> 2^-18 on the product, the
@@ -110,6 +111,22 @@ __device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v, int n_spli
     } else {
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
         *reinterpret_cast<bf16x4*>(dst) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    }
+}
+
+// 8 consecutive outputs of one row (outputs narrower than fp32): ONE 16-B store for 16-bit types, 8 B for fp8, 16 + 8 + 8 B for split rows
+template <typename OutT>
+__device__ __forceinline__ void store_out8(OutT* dst, const f32x4& a, const f32x4& b, int n_split = 0, int col = 0) {
+    if constexpr (std::is_same<OutT, f16x3_t>::value) {
+        store_split8(reinterpret_cast<char*>(dst) - 2 * col, n_split, col, a, b);
+    } else if constexpr (std::is_same<OutT, f16_t>::value) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{pack_f16x2(a[0], a[1]), pack_f16x2(a[2], a[3]), pack_f16x2(b[0], b[1]), pack_f16x2(b[2], b[3])};
+    } else if constexpr (std::is_same<OutT, fp8_t>::value) {
+        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_fp8x2(a[2], a[3], pack_fp8x2(a[0], a[1], 0u, false), true),
+                                               pack_fp8x2(b[2], b[3], pack_fp8x2(b[0], b[1], 0u, false), true)};
+    } else {
+        static_assert(std::is_same<OutT, bf16_t>::value, "store_out8: outputs narrower than fp32");
+        *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
     }
 }
 
@@ -336,19 +353,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                                               int r32, int half, bool vec_ok, char* smem, int wave) {
     if constexpr (!MAX32) {
         if (vec_ok) {
-            constexpr int CH = 8 * TN, RPI = 64 / CH, ITERS = 32 / RPI, LD = (32 * TN + 4) * 4;   // 16-B chunks per row, rows per instruction
+            // W = columns per lane.  4: one 16-B strip read, 16-B (fp32) / 8-B (16-bit) / 4-B (fp8) stores.  8 (outputs narrower than
+            // fp32, N % 8 == 0): two strip reads, ONE 16-B store per lane for 16-bit outputs -- the store tail of a 16-bit epilogue is
+            // store-ISSUE-bound (guide T21: half the instructions at equal bytes halve it), and a wave instruction then covers 8 rows x
+            // 128 B = whole cache lines.  SPRC_EPI_WIDE=0 keeps W = 4 (A/B switch).
+            auto vec_path = [&](auto w_) {
+            constexpr int W = decltype(w_)::value, NV = W / 4;
+            constexpr int CH = 32 * TN / W, RPI = 64 / CH, ITERS = 32 / RPI, LD = (32 * TN + 4) * 4;   // chunks per row, rows per instruction
             const int lane = half * 32 + r32, ch = lane % CH, rsub = lane / CH;
             char* strip = smem + wave * EPI_STRIP_BYTES(TN);
-            const int col = cn0 + wc * TN * 32 + ch * 4;
+            const int col = cn0 + wc * TN * 32 + ch * W;
             const bool col_ok = col < p.N;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias != nullptr && col_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-            f32x4 sv = {1.f, 1.f, 1.f, 1.f};               // fp8 operands: per-output-channel dequantisation
-            const bool scaled = p.w_scale != nullptr;
-            if (scaled && col_ok) {
-                sv = *reinterpret_cast<const f32x4*>(p.w_scale + col);
+            f32x4 bv[NV], sv[NV];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sv[e] *= p.a_scale;
+            for (int j = 0; j < NV; ++j) { bv[j] = f32x4{0.f, 0.f, 0.f, 0.f}; sv[j] = f32x4{1.f, 1.f, 1.f, 1.f}; }
+            if (p.bias != nullptr && col_ok) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + col + 4 * j);
+            }
+            const bool scaled = p.w_scale != nullptr;               // fp8 operands: per-output-channel dequantisation
+            if (scaled && col_ok) {
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    sv[j] = *reinterpret_cast<const f32x4*>(p.w_scale + col + 4 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sv[j][e] *= p.a_scale;
+                }
             }
             // Residual rows are fetched TWO 32-row blocks ahead of their use (the fragments' registers are free here): with the
             // loads of a block issued only when the block was reached, every block paid a full memory round trip -- 23 k cycles
@@ -360,12 +390,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             const int colc = col_ok ? col : 0;
             auto body = [&](auto res_) {
                 constexpr bool RES = decltype(res_)::value;
-                f32x4 rv[2][ITERS];
-                auto load_resid = [&](int mi, f32x4 (&dst)[ITERS]) {
+                f32x4 rv[2][ITERS][NV];
+                auto load_resid = [&](int mi, f32x4 (&dst)[ITERS][NV]) {
 #pragma unroll
                     for (int it = 0; it < ITERS; ++it) {
                         const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, min(block_row(mi, it), p.M - 1));
-                        dst[it] = *reinterpret_cast<const f32x4*>(p.resid + pr * p.ldr + colc);
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) dst[it][j] = *reinterpret_cast<const f32x4*>(p.resid + pr * p.ldr + colc + 4 * j);
                     }
                 };
                 if constexpr (RES) {
@@ -382,23 +413,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                                 f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
 #pragma unroll
                     for (int it = 0; it < ITERS; ++it) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(strip + (it * RPI + rsub) * LD + ch * 16);
+                        f32x4 v[NV];
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(strip + (it * RPI + rsub) * LD + ch * (W * 4) + j * 16);
+#pragma unroll
+                        for (int j = 0; j < NV; ++j)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {       // element-wise on purpose: vector adds become v_pk_add_f32 (slower)
-                            if (scaled) v[e] *= sv[e];
-                            v[e] += bv[e];
+                            if (scaled) v[j][e] *= sv[j][e];
+                            v[j][e] += bv[j][e];
                             if constexpr (ACT == SPRC_ACT_GELU) {
-                                if constexpr (sizeof(T) <= 2) v[e] = gelu_fast(v[e]);
-                                else v[e] = gelu_erf(v[e]);
+                                if constexpr (sizeof(T) <= 2) v[j][e] = gelu_fast(v[j][e]);
+                                else v[j][e] = gelu_erf(v[j][e]);
                             }
-                            if constexpr (ACT == SPRC_ACT_QUICKGELU) v[e] = sizeof(T) <= 2 ? quick_gelu_fast(v[e]) : quick_gelu(v[e]);
-                            if constexpr (RES) v[e] += rv[mi & 1][it][e];
-                            if constexpr (std::is_same<OutT, fp8_t>::value) v[e] *= p.out_scale;
+                            if constexpr (ACT == SPRC_ACT_QUICKGELU) v[j][e] = sizeof(T) <= 2 ? quick_gelu_fast(v[j][e]) : quick_gelu(v[j][e]);
+                            if constexpr (RES) v[j][e] += rv[mi & 1][it][j][e];
+                            if constexpr (std::is_same<OutT, fp8_t>::value) v[j][e] *= p.out_scale;
                         }
                         const int row = block_row(mi, it);
                         if (!(row < p.M && col_ok)) continue;
                         const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, row);
-                        store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v, p.N, col);
+                        if constexpr (W == 8) store_out8<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v[0], v[1], p.N, col);
+                        else store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v[0], p.N, col);
                     }
                     if constexpr (RES) {
                         if (mi + 2 < TM) load_resid(mi + 2, rv[mi & 1]);
@@ -407,6 +443,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             };
             if (p.resid != nullptr) body(std::true_type{});
             else body(std::false_type{});
+            };
+            if constexpr (sizeof(OutT) < 4) {
+                const bool wide_ok = p.epi_wide && (p.N % 8 == 0) && (p.ldc % 8 == 0) && ((uintptr_t)p.C % 16 == 0);
+                if (wide_ok) { vec_path(std::integral_constant<int, 8>{}); return; }
+            }
+            vec_path(std::integral_constant<int, 4>{});
             return;
         }
     }

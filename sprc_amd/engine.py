@@ -468,8 +468,9 @@ class Engine:
 
     # ---- workspaces ------------------------------------------------------------------------
     def _workspace(self, kind: str, B: int) -> torch.Tensor:
-        fn = self.lib.sprc_vit_workspace_bytes if kind == "vit" else self.lib.sprc_qformer_workspace_bytes      # "qf", "qf_image"
-        need = int(fn(C.byref(self.vit if kind == "vit" else self.qf), B))
+        is_vit = kind.startswith("vit")                                                                         # "vit", "vit#1", "qf", "qf_image"
+        fn = self.lib.sprc_vit_workspace_bytes if is_vit else self.lib.sprc_qformer_workspace_bytes
+        need = int(fn(C.byref(self.vit if is_vit else self.qf), B))
         ws = self._ws.get(kind)
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -478,9 +479,10 @@ class Engine:
 
     # ---- forward passes ----------------------------------------------------------------------
     @_on_device
-    def vit_forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, pre_ln_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def vit_forward(self, images: torch.Tensor, out: Optional[torch.Tensor] = None, pre_ln_out: Optional[torch.Tensor] = None, slot: int = 0) -> torch.Tensor:
         """raw[B,257,D] fp32 = ln_vision(ViT(images)).  pre_ln_out (optional, fp32 [B*257, D] or [B,257,D]): receives ln_vision's INPUT
-        (the training step differentiates ln_vision, sprc_amd/train.py)."""
+        (the training step differentiates ln_vision, sprc_amd/train.py).  slot: which activation workspace to use -- two forwards that are
+        in flight on two streams at once (bench.py --vit-overlap 2) need one each."""
         v = self.cfg.vit
         images = images.to(device=self.device, dtype=torch.float32).contiguous()
         B = images.shape[0]
@@ -492,7 +494,7 @@ class Engine:
         try:
             for s in range(0, B, self.max_batch):
                 n = min(self.max_batch, B - s)
-                ws = self._workspace("vit", n)
+                ws = self._workspace("vit" if slot == 0 else f"vit#{slot}", n)
                 if pre_ln_out is not None:
                     self.vit.pre_ln_out = pre_ln_out.data_ptr() + s * v.tokens * v.width * 4
                 L.check(self.lib.sprc_vit_forward(C.byref(self.vit), images[s:s + n].data_ptr(), n, raw[s:s + n].data_ptr(),
