@@ -339,6 +339,15 @@ __device__ __forceinline__ void tile_origin(int vb, int nwg, int tiles_m, int ti
     }
 }
 
+// The kernel's parameter block through a LAUNDERED kernarg pointer: loads through it are scheduled where they are written (the compiler
+// cannot merge them with the entry-time loads of the by-value parameter), so a phase can fetch its own parameters when it starts.
+typedef const __attribute__((address_space(4))) GemmParams* kparams_t;
+__device__ __forceinline__ kparams_t kernarg_params() {
+    kparams_t kp = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
 // ---- epilogue (shared).  Transposed 32x32 D layout: m = rbase + (lane&31),  n = cbase + 8*(r>>2) + 4*(lane>>5) + (r&3) ----
 // Each wave transposes its accumulators through a private LDS strip (32 rows x (32 TN + 4) floats: the padding makes both
 // the ds_write_b128 of the fragment layout and the row-major ds_read_b128 conflict-free) so that global memory sees FULL
@@ -371,7 +380,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int j = 0; j < NV; ++j) bv[j] = *reinterpret_cast<const f32x4*>(p.bias + col + 4 * j);
             }
-            const bool scaled = p.w_scale != nullptr;               // fp8 operands: per-output-channel dequantisation
+            const bool scaled = sizeof(T) == 1 && p.w_scale != nullptr;     // fp8 operands: per-output-channel dequantisation (a compile-time
+                                                                            // false elsewhere: the run-time flag cost a v_mul + v_cndmask per element)
             if (scaled && col_ok) {
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
@@ -388,15 +398,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             // (C may alias the residual: every element is read by the lane that writes it, before it writes it.)
             auto block_row = [&](int mi, int it) { return cm0 + (wr * TM + mi) * 32 + it * RPI + rsub; };
             const int colc = col_ok ? col : 0;
+            // Row addressing without branches or 64-bit multiplies (the .s of the first form: per store a uniform branch on "is there a row
+            // map", two v_mul_lo_u32 + a v_mad_u64_u32 -- quarter-rate -- and 64-bit adds): the row map in its branch-free form (identity =
+            // shift 31, stride 0), rows taken RELATIVE to the tile's first mapped row, so that a row's offset is one 24-bit multiply
+            // (launchers check the ranges: epi_fits_u32) added to a tile-uniform base pointer.
+            const int nz = ~(p.c_shift >> 31), sh = p.c_shift & 31, msk = (int)((1u << sh) - 1u), cstr = p.c_stride & nz, coff = p.c_off & nz;
+            auto mrow = [&](int r) { return __mul24(r >> sh, cstr) + (r & msk) + coff; };
+            const int row0m = mrow(cm0);
+            OutT* const cbase = reinterpret_cast<OutT*>(p.C) + (int64_t)row0m * p.ldc;
+            const float* const rbase = p.resid + (int64_t)row0m * p.ldr;
+            const uint32_t ldc32 = (uint32_t)p.ldc, ldr32 = (uint32_t)p.ldr;
             auto body = [&](auto res_) {
                 constexpr bool RES = decltype(res_)::value;
                 f32x4 rv[2][ITERS][NV];
                 auto load_resid = [&](int mi, f32x4 (&dst)[ITERS][NV]) {
 #pragma unroll
                     for (int it = 0; it < ITERS; ++it) {
-                        const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, min(block_row(mi, it), p.M - 1));
+                        const uint32_t ro = __umul24((uint32_t)(mrow(min(block_row(mi, it), p.M - 1)) - row0m), ldr32) + (uint32_t)colc;
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) dst[it][j] = *reinterpret_cast<const f32x4*>(p.resid + pr * p.ldr + colc + 4 * j);
+                        for (int j = 0; j < NV; ++j) dst[it][j] = *reinterpret_cast<const f32x4*>(rbase + ro + 4 * j);
                     }
                 };
                 if constexpr (RES) {
@@ -432,9 +452,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                         }
                         const int row = block_row(mi, it);
                         if (!(row < p.M && col_ok)) continue;
-                        const int64_t pr = map_row_s(p.c_shift, p.c_stride, p.c_off, row);
-                        if constexpr (W == 8) store_out8<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v[0], v[1], p.N, col);
-                        else store_out4<OutT>(reinterpret_cast<OutT*>(p.C) + pr * p.ldc + col, v[0], p.N, col);
+                        OutT* const dst = cbase + (__umul24((uint32_t)(mrow(row) - row0m), ldc32) + (uint32_t)col);
+                        if constexpr (W == 8) store_out8<OutT>(dst, v[0], v[1], p.N, col);
+                        else store_out4<OutT>(dst, v[0], p.N, col);
                     }
                     if constexpr (RES) {
                         if (mi + 2 < TM) load_resid(mi + 2, rv[mi & 1]);
@@ -541,6 +561,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmParams p) {
     // no per-load address VALU, and they issue 2-3x faster than global_load_lds with 64-bit lane addresses.
     int m0, n0;
     tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
+    m0 = __builtin_amdgcn_readfirstlane(m0);                // (computed on the VALU: pinned to SGPRs, see gemm_anti_kernel)
+    n0 = __builtin_amdgcn_readfirstlane(n0);
     const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
     const char* a_base = p.A + a_row0 * p.lda_b;            // resources are rebuilt from these at each use (loop-invariant SGPRs)
     const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
@@ -731,12 +753,19 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
 
     int vb = blockIdx.x;
-    if (p.dual && vb >= p.nwg0) {                           // second product of a paired launch
+    const bool second = p.dual && vb >= p.nwg0;             // second product of a paired launch
+    if (second) {
         vb -= p.nwg0;
-        p.W = p.W2; p.bias = p.bias2; p.a_off = p.a_off2; p.c_off = p.c_off2;
+        p.W = p.W2; p.a_off = p.a_off2;
     }
     int m0, n0;
     tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
+    // tile_origin divides in floating point, i.e. on the VALU: its (wave-uniform) results sit in VGPRs, and whether hipcc moves them to
+    // SGPRs or builds everything downstream -- the two buffer descriptors included -- on the VALU depends on how many vector uses the
+    // rest of the kernel has for them.  A descriptor in VGPRs is a v_readfirstlane waterfall loop around EVERY LDS-DMA load (guide T20;
+    // seen after an epilogue change: 16 loops per K-tile pair, every product 3-9 % slower).  Pin them.
+    m0 = __builtin_amdgcn_readfirstlane(m0);
+    n0 = __builtin_amdgcn_readfirstlane(n0);
     f32x16 acc[TM][TN];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -987,9 +1016,15 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     }
     if (wr == 0) barrier();                                 // G1 spent its extra barrier up front
     if constexpr (STAMP) tile_ts[2] = __builtin_amdgcn_s_memtime();
-    const bool vec_ok = (p.N % 4 == 0) && (p.ldc % 4 == 0) && (p.resid == nullptr || p.ldr % 4 == 0) &&
-                        ((uintptr_t)p.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)p.bias % 16 == 0) && ((uintptr_t)p.resid % 16 == 0);
-    gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(p, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
+    // The epilogue reads ITS parameters (output / residual / bias pointers, leading dimensions, the row map, scales) through the laundered
+    // kernarg pointer, after the K loop: held in SGPRs from kernel entry they are live across the K loop, and one uniform value too
+    // many there makes hipcc keep the two buffer descriptors in VGPRs -- a v_readfirstlane waterfall loop around every LDS-DMA load of the
+    // steady state (seen: 16 per K-tile pair, the whole step 90.8 -> 93.9 ms, after an epilogue change added a handful of uniform values).
+    GemmParams pe = *(const GemmParams*)kernarg_params();
+    if (second) { pe.bias = pe.bias2; pe.c_off = pe.c_off2; }
+    const bool vec_ok = (pe.N % 4 == 0) && (pe.ldc % 4 == 0) && (pe.resid == nullptr || pe.ldr % 4 == 0) &&
+                        ((uintptr_t)pe.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)pe.bias % 16 == 0) && ((uintptr_t)pe.resid % 16 == 0);
+    gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(pe, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's stores have left the wave
         tile_ts[3] = __builtin_amdgcn_s_memtime();
@@ -1127,9 +1162,21 @@ static bool fits_u32(const GemmParams& p) {
            p.lda_b < (1 << 24) && p.ldw_b < (1 << 24);          // the 256 x 256 kernel forms row offsets with 24-bit multiplies
 }
 
+// The vector epilogue forms a row's offset from the tile's first row with 24-bit multiplies in 32 bits: row-map stride, ldc and ldr < 2^24,
+// and the rows of one (<= 256-row) tile within 4 GiB of its first row in C and in the residual.
+static bool epi_fits_u32(const GemmParams& p) {
+    const int64_t span = p.c_shift < 0 ? 256 : (int64_t)((256 >> p.c_shift) + 2) * p.c_stride;
+    return p.ldc < (1 << 24) && p.ldr < (1 << 24) && (p.c_shift < 0 || (p.c_stride >= 0 && p.c_stride < (1 << 23))) &&
+           span * (p.ldc > p.ldr ? p.ldc : p.ldr) * 4 + ((int64_t)p.N + 256) * 4 < ((int64_t)1 << 32);
+}
+
 template <typename T, typename OutT, int ACT, bool MAX32, bool MIX = false>
 static int launch(const GemmParams& p, hipStream_t st) {
     static const int forced = env_int("SPRC_GEMM_TILE", 0);
+    if (!MAX32 && !epi_fits_u32(p)) {
+        set_error("sprc_gemm: ldc / ldr / row-map stride too large for the epilogue's 32-bit tile offsets (ldc=%lld ldr=%lld stride=%d)", (long long)p.ldc, (long long)p.ldr, p.c_stride);
+        return SPRC_EUNSUPPORTED;
+    }
     const int keff = MIX ? p.K + p.k8 / 2 : p.K;                // reduction length in units of 16-bit elements (time ~ bytes of a row)
     int cfg = forced;
     if constexpr (sizeof(T) == 2 && !MAX32 && !MIX && !std::is_same<OutT, fp8_t>::value) {
