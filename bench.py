@@ -505,14 +505,18 @@ def main():
         # committed rocprofv3 passes over this same command (tools/profile_bench.sh -> profiles/r01_traffic.json)
         # -- and only when that profile was taken on THIS build (it records the hash of the kernel sources): otherwise null
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, "profiles", "r04_traffic.json")
-        if a.dtype == "fp16" and a.backbone == "pretrain" and a.vit_streams == 1 and os.path.exists(tj) and pe.launches and not os.environ.get("SPRC_X3_OFF"):
-            with open(tj) as f:
-                tr = json.load(f)
-            if tr.get("kernel_source_sha") == kernel_source_sha():
-                traffic = round(tr["gemm_bytes_per_step"]["total"] / (pe.launches / n_prof), 1)
-                traffic_src = ("profiles/r04_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only "
-                               "passes over this command on this build: kernel_source_sha %s)" % tr["kernel_source_sha"][:12])
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_traffic.json")), reverse=True)       # the newest round's first
+        if a.dtype == "fp16" and a.backbone == "pretrain" and a.vit_streams == 1 and a.qf_group == 1 and cands and pe.launches and not os.environ.get("SPRC_X3_OFF"):
+            sha = kernel_source_sha()
+            for tj in cands:
+                with open(tj) as f:
+                    tr = json.load(f)
+                if tr.get("kernel_source_sha") == sha:
+                    traffic = round(tr["gemm_bytes_per_step"]["total"] / (pe.launches / n_prof), 1)
+                    traffic_src = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate counter-only "
+                                   "passes over this command on this build: kernel_source_sha %s)" % (os.path.basename(tj), sha[:12]))
+                    break
         # whole-step utilisation: ALGORITHMIC flops of one step over the step time, against the dtype's peak
         step_tflop = (BATCH * GFLOP_PER_IMAGE[a.backbone] + Q_PER_STEP * GFLOP_PER_QUERY[a.backbone]) * 1e-3 \
             + Q_PER_STEP * GALLERY * FLOP_PER_PAIR * 1e-12
