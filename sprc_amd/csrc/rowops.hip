@@ -117,60 +117,6 @@ __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_kernel(LnParams
                     p.y16 ? (char*)p.y16 + yr * p.ld16 * (KIND ? 2 : 4) : nullptr, nch, lane);
 }
 
-// 16-bit-operand-copy LayerNorm with EIGHT columns per lane: two 16-B loads and ONE 16-B store per lane and chunk (the 8-B stores of
-// layernorm_kernel<1|2> run at 0.5-0.7x the 16-B rate: MI355X_MICROARCH.md, store flavours).  The ViT's LayerNorms (no fp32 copy, no
-// fused add; D = 1408 / 1024) take this kernel; statistics as above (fp32, two-pass), per-lane partial sums over other columns.
-constexpr int MAXC8 = 4;          // 8-column chunks per lane -> D <= 64*8*4 = 2048
-template <bool F16>
-__global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm16w_kernel(LnParams p) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= p.M) return;
-    const int nch = p.D >> 3;
-    const float4* x = reinterpret_cast<const float4*>(p.x + map_row(p.xmap, row) * p.ldx);
-    float4 v[MAXC8][2];
-#pragma unroll
-    for (int c = 0; c < MAXC8; ++c) {
-        const int i = lane + c * 64;
-        v[c][0] = (i < nch) ? x[2 * i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        v[c][1] = (i < nch) ? x[2 * i + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXC8; ++c)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) s += (v[c][h].x + v[c][h].y) + (v[c][h].z + v[c][h].w);
-    const float mean = wave_sum(s) / (float)p.D;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < MAXC8; ++c) {
-        if (lane + c * 64 < nch) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float a = v[c][h].x - mean, b = v[c][h].y - mean, cc = v[c][h].z - mean, d = v[c][h].w - mean;
-                q += (a * a + b * b) + (cc * cc + d * d);
-            }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)p.D + p.eps);
-    uint4* y = reinterpret_cast<uint4*>((char*)p.y16 + map_row(p.ymap, row) * p.ld16 * 2);
-#pragma unroll
-    for (int c = 0; c < MAXC8; ++c) {
-        const int i = lane + c * 64;
-        if (i < nch) {
-            uint32_t pk[4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 g = reinterpret_cast<const float4*>(p.gamma)[2 * i + h];
-                const float4 b = reinterpret_cast<const float4*>(p.beta)[2 * i + h];
-                pk[2 * h] = pack16x2<F16>((v[c][h].x - mean) * rstd * g.x + b.x, (v[c][h].y - mean) * rstd * g.y + b.y);
-                pk[2 * h + 1] = pack16x2<F16>((v[c][h].z - mean) * rstd * g.z + b.z, (v[c][h].w - mean) * rstd * g.w + b.w);
-            }
-            y[i] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        }
-    }
-}
-
 // LayerNorm whose operand copy is e4m3fn: y8 = sat(LN(x) * q_scale)  (q_scale = 1 / the consumer GEMM's a_scale)
 
 __global__ __launch_bounds__(64 * ROWS_PER_BLOCK) void layernorm_fp8_kernel(LnParams p, float q_scale) {
@@ -400,7 +346,6 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
     SPRC_REQUIRE(a->sum32 == nullptr || (a->add16 != nullptr && a->ld_sum % 4 == 0), "sprc_layernorm: sum32 needs add16 and ld_sum % 4 == 0");
     LnParams p{a->M, a->D, a->x, a->ldx, a->xmap, a->gamma, a->beta, a->eps, a->y32, a->ld32, a->ymap, a->y16, a->ld16,
                reinterpret_cast<const _Float16*>(a->add16), a->ld_add, a->sum32, a->ld_sum};
-    static const int ln_wide = [] { const char* e = getenv("SPRC_LN_WIDE"); return e ? atoi(e) : 1; }();      // 0: the 8-B-store kernel everywhere (A/B switch)
     const dim3 grid((a->M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), block(64 * ROWS_PER_BLOCK);
     ProfScope prof(SPRC_K_ROWOPS, (hipStream_t)s, 8.0 * a->M * (double)a->D,
                    (double)a->M * a->D * (4.0 + (a->y32 ? 4.0 : 0.0) + (a->y16 ? (a->out_dtype == SPRC_F16X3 ? 4.0 : (double)dtype_size(a->out_dtype)) : 0.0) +
@@ -409,11 +354,6 @@ extern "C" int sprc_layernorm(const sprc_layernorm_args* a, sprc_stream s) {
         SPRC_REQUIRE(a->y16 != nullptr && a->y16_scale > 0.f && a->add16 == nullptr && ((uintptr_t)a->y16 % 4) == 0,
                      "sprc_layernorm(fp8): needs y16, y16_scale > 0 and no fused add");
         hipLaunchKernelGGL(layernorm_fp8_kernel, grid, block, 0, (hipStream_t)s, p, a->y16_scale);
-    } else if ((a->out_dtype == SPRC_BF16 || a->out_dtype == SPRC_F16) && ln_wide && a->y32 == nullptr && a->y16 != nullptr && a->add16 == nullptr &&
-               a->D % 8 == 0 && a->ld16 % 8 == 0 && ((uintptr_t)a->y16 % 16) == 0 && ((uintptr_t)a->x % 16) == 0 && ((uintptr_t)a->gamma % 16) == 0 &&
-               ((uintptr_t)a->beta % 16) == 0) {
-        if (a->out_dtype == SPRC_F16) hipLaunchKernelGGL(layernorm16w_kernel<true>, grid, block, 0, (hipStream_t)s, p);
-        else hipLaunchKernelGGL(layernorm16w_kernel<false>, grid, block, 0, (hipStream_t)s, p);
     } else if (a->out_dtype == SPRC_BF16) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, (hipStream_t)s, p);
     else if (a->out_dtype == SPRC_F16) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, (hipStream_t)s, p);
     else if (a->out_dtype == SPRC_F16X3) {
