@@ -47,3 +47,15 @@ def test_bench_line_through_a_one_rank_rccl_group():
     c = d["config"]
     assert c["rccl_ranks"] == 1 and c["backend"] == "rccl" and c["per_rank_ms_per_step"] == [d["ms_per_step"]]
     assert d["n_gpus"] == 1 and 500 < d["value"] < 5000
+
+
+def test_bench_line_with_grouped_qformer_stage():
+    """`--qf-group G`: the ViT runs per step, the Q-Former stage (gallery-side pass, fusion, ranking) once per G steps on their G x 128 images and
+    G x 233 queries, a last partial group flushed inside the timed region: the line keeps the contract (value from the step time, per-step class
+    figures from the instrumented group)."""
+    d = _run("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-recall", "--qf-group", "2")
+    assert d["config"]["qformer_group"] == 2 and d["steps"] == 5
+    assert d["value"] == pytest.approx(128.0 / (d["ms_per_step"] * 1e-3), rel=1e-3) and 500 < d["value"] < 5000
+    r = d["roofline"]
+    assert 0.2 < r["frac"] < 0.6 and r["traffic"] is None                 # the committed counter profile belongs to the ungrouped command
+    assert d["kernels"]["gemm_bf16"]["launches_per_step"] > 150
