@@ -1,5 +1,5 @@
-"""The bench line the driver parses: the committed `profiles/r04_bench_n1.json` (an unedited `python bench.py` line; its
-`roofline.traffic` is what bench.py itself reads from profiles/r04_traffic.json) must carry every field of the measurement contract,
+"""The bench line the driver parses: the committed `profiles/r05_bench_n1.json` (an unedited `python bench.py` line; its
+`roofline.traffic` is what bench.py itself reads from profiles/r05_traffic.json) must carry every field of the measurement contract,
 and the roofline numbers must be self-consistent and agree with the committed rocprofv3 summaries of the same build."""
 import json
 from pathlib import Path
@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def test_committed_bench_line_follows_the_contract():
-    d = json.loads((ROOT / "profiles" / "r04_bench_n1.json").read_text())
+    d = json.loads((ROOT / "profiles" / "r05_bench_n1.json").read_text())
     base = json.loads((ROOT / "BASELINE.json").read_text())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -40,24 +40,30 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "encode_images_per_s", "fuse_rank_queries_per_s"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
-    # BASELINE.json's metric names Recall@K: the line carries it for the planted CIRR-val-sized case (bench.py --recall)
+    # BASELINE.json's metric names Recall@K: the line carries it by default (round 5), against the scores the UNMODIFIED REFERENCE produced for
+    # every 22nd query of the planted CIRR-val-sized case, on fp32-valued and on fp16-valued trunk weights (tests/golden/planted_c2_subset_eva*.npz)
     rc = d["recall"]
-    assert rc["equal_recall_at_1_5_10"] is True and rc["engine"]["recall_at_10"] == rc["fp32_engine_as_reference"]["recall_at_10"] > 20.0
-    assert abs(rc["engine"]["recall_at_50"] - rc["fp32_engine_as_reference"]["recall_at_50"]) < 0.3 and rc["rms_dsim"] < 4e-4
+    assert rc["equal_recall_at_1_5_10"] is True and "REFERENCE" in rc["case"]
+    for key in ("fp32_weights", "fp16_valued_trunk"):
+        sub = rc[key]
+        assert sub["scores"] == 191 * 2297 and sub["equal_recall_at_1_5_10"] and sub["equal_subset_recalls"] and sub["top1_image_equal_pct"] == 100.0
+        assert sub["engine"]["recall_at_10"] == sub["reference"]["recall_at_10"] > 20.0
+        assert abs(sub["engine"]["recall_at_50"] - sub["reference"]["recall_at_50"]) < 0.6 and sub["rms_dsim"] < 3e-4      # one query of 191 = 0.52 points
+    assert rc["fp16_valued_trunk"]["max_abs_dsim"] < 1.1e-3 and rc["fp16_valued_trunk"]["scores_over_1e-3"] <= 3
     assert d["config"]["per_rank_ms_per_step"] == [d["ms_per_step"]]
 
 
 def test_committed_rocprof_summary_agrees_with_the_bench_line():
     import csv
-    d = json.loads((ROOT / "profiles" / "r04_bench_n1.json").read_text())
-    rows = list(csv.DictReader((ROOT / "profiles" / "r04_bench_kernel_stats.csv").open()))
+    d = json.loads((ROOT / "profiles" / "r05_bench_n1.json").read_text())
+    rows = list(csv.DictReader((ROOT / "profiles" / "r05_bench_kernel_stats.csv").open()))
     gemm_ms = sum(float(r["TotalDurationNs"]) for r in rows if "gemm" in r["Name"] or "splitk" in r["Name"]) / 4e6   # 4 steps profiled
     ev = d["kernels"]["gemm_bf16"]["ms_per_step"]
     assert abs(gemm_ms - ev) / ev < 0.03, (gemm_ms, ev)
 
 
 def test_committed_counter_summary_has_the_utilisation_numbers():
-    d = json.loads((ROOT / "profiles" / "r04_pmc.json").read_text())
+    d = json.loads((ROOT / "profiles" / "r05_pmc.json").read_text())
     g = d["classes"]["gemm_anti"]["derived"]
     for k in ("mfma_busy_frac", "mfma_busy_frac_of_wall_at_2p4GHz", "effective_clock_GHz_upper_bound", "lds_bank_conflict_frac",
               "sq_wait_any_frac_of_wave_cycles", "hbm_side_GBs"):
@@ -65,19 +71,19 @@ def test_committed_counter_summary_has_the_utilisation_numbers():
     assert 0.2 < g["mfma_busy_frac_of_wall_at_2p4GHz"] <= g["mfma_busy_frac"] < 1.0 and 1.0 < g["effective_clock_GHz_upper_bound"] < 2.45
     # the clock ratio is only formed for long dispatches (it read 3.3 GHz on 12-us launches)
     assert "effective_clock_GHz_upper_bound" not in d["classes"]["gemm_128"]["derived"]
-    t = json.loads((ROOT / "profiles" / "r04_traffic.json").read_text())
-    b = json.loads((ROOT / "profiles" / "r04_bench_n1.json").read_text())
+    t = json.loads((ROOT / "profiles" / "r05_traffic.json").read_text())
+    b = json.loads((ROOT / "profiles" / "r05_bench_n1.json").read_text())
     per_launch = t["gemm_bytes_per_step"]["total"] / b["kernels"]["gemm_bf16"]["launches_per_step"]
     assert abs(per_launch - b["roofline"]["traffic"]) / per_launch < 1e-3
     assert t["kernel_source_sha"][:12] in b["roofline"]["traffic_source"]
 
 
 def test_fp8_bench_line_is_priced_against_the_fp8_peak():
-    d = json.loads((ROOT / "profiles" / "r04_bench_vitL_fp8.json").read_text())
+    d = json.loads((ROOT / "profiles" / "r05_bench_vitL_fp8.json").read_text())
     assert d["dtype"] == "fp8" and d["roofline"]["peak"] == 5000.0
-    b = json.loads((ROOT / "profiles" / "r04_bench_vitL_bf16.json").read_text())
+    b = json.loads((ROOT / "profiles" / "r05_bench_vitL_bf16.json").read_text())
     assert d["value"] > b["value"]
-    c5 = json.loads((ROOT / "profiles" / "r04_bench_c5_slice_fp8.json").read_text())
+    c5 = json.loads((ROOT / "profiles" / "r05_bench_c5_slice_fp8.json").read_text())
     assert c5["config"]["shard"] == 125000 and c5["config"]["queries"] == 10000 and "EXTRAPOLATED" in c5["config"]["workload"]
     assert c5["steps"] >= 200                            # 200 timed encode steps behind the per-step figure, not 20
     t = c5["config"]["shard"] / c5["config"]["batch"] * c5["ms_per_step"] * 1e-3 + c5["config"]["fuse_rank_ms"] * 1e-3
@@ -86,6 +92,6 @@ def test_fp8_bench_line_is_priced_against_the_fp8_peak():
 
 def test_same_box_dtype_comparison_is_on_record():
     """fp16 (headline) vs bf16 vs fp16 without the split-precision Q-Former, same box, same build: what parity costs."""
-    f16, b16, single = (json.loads((ROOT / "profiles" / f"r04_bench_n1{t}.json").read_text()) for t in ("", "_bf16", "_fp16_single"))
+    f16, b16, single = (json.loads((ROOT / "profiles" / f"r05_bench_n1{t}.json").read_text()) for t in ("", "_bf16", "_fp16_single"))
     assert f16["dtype"] == "fp16" and b16["dtype"] == "bf16" and single["dtype"] == "fp16"
     assert b16["value"] > single["value"] > f16["value"] > 0.85 * b16["value"]

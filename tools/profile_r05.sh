@@ -31,7 +31,7 @@ python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-recall 2>/d
 bash tools/trace_top.sh --pipeline 0 --qf-streams 1 --no-recall > $O/trace_top.txt 2>&1
 python tools/blas_ref.py fp16 2>&1 | grep -v amdgpu > $O/blas_ref_fp16.txt
 python tools/gemm_split_bench.py 14912,768,3072 14912,768,768 7456,768,768 4096,3072,768 4096,768,3072 32896,9216,1408 2>&1 | grep -v amdgpu > $O/gemm_split_bench.txt
-python tests/bench_train_step.py 32 5 2 fp16 2>&1 | grep -v "amdgpu\|Warning\|warn" | tail -6 > $O/train_step.txt
+for pr in fp32 fp16; do python tests/bench_train_step.py 32 5 2 fp16 $pr 2>&1 | grep "train step, HIP"; done > $O/train_step.txt
 for g in 1 4; do echo "--qf-group $g"; python bench.py --steps 20 --warmup 8 --no-cpu-baseline --no-recall --qf-group $g 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['step_frac'])"; done > $O/qf_group_ab.txt
 python tools/qf_shapes.py 2>&1 | grep -v amdgpu.ids > $O/qf_shapes.txt
 rm -rf $O/pb/kt $O/pb/pmc_* $O/pmc/p? $O/pmc/kt $R/gpurun_out/trace_top/kt
