@@ -742,24 +742,33 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     constexpr bool FP8 = sizeof(T) == 1;
     constexpr int WN = 4, TM = 4, TN = 2, KTB = 128;
     constexpr int BM = 256, BN = 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // PERSISTENT tile loop: workgroup b takes tiles b, b + gridDim, ... (the launcher sizes the grid: one workgroup per tile, or -- SPRC_GEMM_PERSIST
+    // -- one per CU; gridDim is a multiple of 8 there, so a workgroup's tiles keep its XCD).  Nothing but the tile index lives across an
+    // iteration: every tile re-derives its state from the (laundered) kernarg pointer and a laundered thread index, so that no
+    // loop-invariant register survives the epilogue.
+    int total_tiles;
+    { kparams_t k0 = kernarg_params(); total_tiles = k0->tiles_m * k0->tiles_n * (k0->dual ? 2 : 1); }
+    for (int vb0 = blockIdx.x; vb0 < total_tiles; vb0 += (int)gridDim.x) {
+    kparams_t kq = kernarg_params();
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int wr = __builtin_amdgcn_readfirstlane(wave / WN), wc = wave % WN;   // wr doubles as the phase group (SGPR: barriers under it)
     const int r32 = lane & 31, half = lane >> 5;
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int nt16 = MIX ? p.K / 64 : 0;                    // MIX: fp16 K-tiles [0, nt16) (even), then e4m3 K-tiles
-    const int nt = FP8 ? p.K / 128 : p.K / 64 + (MIX ? p.k8 / 128 : 0);             // K-tiles of 128 bytes
+    const int nwg = kq->tiles_m * kq->tiles_n;
+    const int nt16 = MIX ? kq->K / 64 : 0;                  // MIX: fp16 K-tiles [0, nt16) (even), then e4m3 K-tiles
+    const int nt = FP8 ? kq->K / 128 : kq->K / 64 + (MIX ? kq->k8 / 128 : 0);       // K-tiles of 128 bytes
     uint64_t tile_ts[4] = {0, 0, 0, 0};                      // STAMP build: entry | prologue done | K loop done | epilogue done
     uint64_t pro_ts[3] = {0, 0, 0};                         // STAMP build, inside the prologue: setup done | loads issued | loads landed
     if constexpr (STAMP) tile_ts[0] = __builtin_amdgcn_s_memtime();
 
-    int vb = blockIdx.x;
-    const bool second = p.dual && vb >= p.nwg0;             // second product of a paired launch
-    if (second) {
-        vb -= p.nwg0;
-        p.W = p.W2; p.a_off = p.a_off2;
-    }
+    int vb = vb0;
+    const bool second = kq->dual && vb >= kq->nwg0;         // second product of a paired launch
+    if (second) vb -= kq->nwg0;
+    const char* const w_sel = second ? kq->W2 : kq->W;
+    const int a_off_s = second ? kq->a_off2 : kq->a_off;
     int m0, n0;
-    tile_origin(vb, nwg, p.tiles_m, p.tiles_n, BM, BN, p.order, m0, n0);
+    tile_origin(vb, nwg, kq->tiles_m, kq->tiles_n, BM, BN, kq->order, m0, n0);
     // tile_origin divides in floating point, i.e. on the VALU: its (wave-uniform) results sit in VGPRs, and whether hipcc moves them to
     // SGPRs or builds everything downstream -- the two buffer descriptors included -- on the VALU depends on how many vector uses the
     // rest of the kernel has for them.  A descriptor in VGPRs is a v_readfirstlane waterfall loop around EVERY LDS-DMA load (guide T20;
@@ -795,12 +804,12 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     const uint32_t wg_off = (uint32_t)__builtin_amdgcn_readfirstlane((wave & 3) * 1024);
     const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of piece q in its operand
     uint32_t pc_off[4][2];                                  // byte offset of this lane's 16-B chunk from the tile's first row (K-tile 0)
-    const int64_t a_row0 = map_row_s(p.a_shift, p.a_stride, p.a_off, m0);
-    const char* a_base = p.A + a_row0 * p.lda_b;
-    const char* w_base = p.W + (int64_t)n0 * p.ldw_b;
+    const int64_t a_row0 = map_row_s(kq->a_shift, kq->a_stride, a_off_s, m0);
+    const char* a_base = kq->A + a_row0 * kq->lda_b;
+    const char* w_base = w_sel + (int64_t)n0 * kq->ldw_b;
     // everything up to the first load is exposed once per tile (s_memtime: 2-3.5 k cycles of a 75 k tile before this diet):
     // offsets are < 2^32 by fits_u32(), rows of a tile < 2^8 -> 24-bit multiplies on the plain row map
-    const bool plain_a = p.a_shift < 0;
+    const bool plain_a = kq->a_shift < 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
 #pragma unroll
@@ -809,10 +818,10 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
             const int slot = (c & 7) ^ ((row >> 1) & 7);
             uint32_t o;
             if (q >= 2) {
-                if (plain_a) o = __umul24((uint32_t)(min(m0 + row, p.M - 1) - m0), (uint32_t)p.lda_b);
-                else o = (uint32_t)((map_row_s(p.a_shift, p.a_stride, p.a_off, min(m0 + row, p.M - 1)) - a_row0) * p.lda_b);
+                if (plain_a) o = __umul24((uint32_t)(min(m0 + row, kq->M - 1) - m0), (uint32_t)kq->lda_b);
+                else o = (uint32_t)((map_row_s(kq->a_shift, kq->a_stride, a_off_s, min(m0 + row, kq->M - 1)) - a_row0) * kq->lda_b);
             } else {
-                o = __umul24((uint32_t)(min(n0 + row, p.N - 1) - n0), (uint32_t)p.ldw_b);
+                o = __umul24((uint32_t)(min(n0 + row, kq->N - 1) - n0), (uint32_t)kq->ldw_b);
             }
             pc_off[q][j] = o + slot * 16;
         }
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     };
     auto stamp = [&](auto i_, int t) {
         if constexpr (STAMP) {
-            if (t == 8 && ((p.ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
+            if (t == 8 && ((kq->ksplit >> decltype(i_)::value) & 1)) ts[decltype(i_)::value] = __builtin_amdgcn_s_memtime();   // ksplit = stamp mask here
         }
     };
     // NC(t,1) stages K-tile t+1 (G0) or t+2 (G1): tile index and stage parity of that piece pair
@@ -1029,18 +1038,23 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's stores have left the wave
         tile_ts[3] = __builtin_amdgcn_s_memtime();
         if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) {
-            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + (wave >> 2) * 16;
+            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(kq->resid)) + (wave >> 2) * 16;
 #pragma unroll
             for (int i = 0; i < 12; ++i) o[i] = ts[i];
         }
         // whole-tile timeline of a third-round workgroup (steady state): slots 32.. of the resid buffer
-        if ((int)blockIdx.x == p.nwg0 && lane == 0 && (wave & 3) == 0) {      // nwg0 = the workgroup to time (STAMP build)
-            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(p.resid)) + 32 + (wave >> 2) * 4;
+        if ((int)blockIdx.x == kq->nwg0 && lane == 0 && (wave & 3) == 0) {      // nwg0 = the workgroup to time (STAMP build)
+            uint64_t* o = reinterpret_cast<uint64_t*>(const_cast<float*>(kq->resid)) + 32 + (wave >> 2) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = tile_ts[i];
 #pragma unroll
             for (int i = 0; i < 3; ++i) o[8 + i] = pro_ts[i];
         }
+    }
+    // next tile of this workgroup: its first LDS-DMA loads overwrite the strips the epilogue transposed through -- every wave has to be done
+    // reading them.  The epilogue's stores stay in flight: loads return in order among themselves, so a counted vmcnt wait that still sees
+    // older stores waits longer, never shorter.
+    if (vb0 + (int)gridDim.x < total_tiles) barrier();
     }
 }
 
@@ -1145,7 +1159,13 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     static const int order = env_int("SPRC_GEMM_ORDER", 4);     // W-resident groups of 4 n-tiles: +8 % on N = 9216, neutral else
     p.order = order;
     p.nwg0 = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(p.nwg0 * (p.dual ? 2 : 1)), dim3(512), LDS, st, p);
+    // one workgroup per CU that walks its tiles (SPRC_GEMM_PERSIST=0: one workgroup per tile, the A/B switch).  Same box, pipelined bench step:
+    // 90.13 / 90.24 ms (the kernel without the tile loop) -> 90.48 / 90.38 (this kernel, one workgroup per tile) -> 89.23 / 89.40 (persistent);
+    // the class time of the serial, instrumented steps does not move (79.5 ms): what is saved are workgroup hand-overs while the Q-Former's
+    // side-stream kernels compete for CUs (profiles/r05_persist_ab.txt)
+    static const int persist = env_int("SPRC_GEMM_PERSIST", 1);
+    const int total = p.nwg0 * (p.dual ? 2 : 1), ncu = num_cus() & ~7;
+    hipLaunchKernelGGL(kern, dim3(persist && ncu > 0 && total > ncu ? ncu : total), dim3(512), LDS, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm(anti)");
     return SPRC_OK;
 }

@@ -3,7 +3,7 @@
 Guards a regression no parity test can see: whether hipcc keeps the two buffer descriptors of the LDS-DMA loads in SGPRs depends on unrelated
 code (round 5: an epilogue change made it build them on the VALU -- a v_readfirstlane waterfall loop around every load of the steady state,
 every product 3-9 % slower, all tests green).  A healthy loop is 64 MFMAs per K-tile pair, no waterfall loop, no v_readlane (spilled SGPRs),
-no VALU at all."""
+no VALU beyond one compare of the wave-group flag."""
 import importlib.util
 import shutil
 import subprocess
@@ -29,5 +29,5 @@ def test_steady_k_loop_has_no_waterfall_no_spill_no_valu(tmp_path):
     for what, name in ks.KERNELS.items():
         st = ks.steady_loop(lines, name)
         assert st is not None, f"{what}: kernel not in the listing"
-        assert st["mfma"] == 64 and st["waterfall"] == 0 and st["readfirstlane"] == 0 and st["readlane"] == 0 and st["valu"] == 0, (what, st)
-        assert st["len"] <= 230, (what, st)          # 207 instructions this round: 64 MFMA, 48 ds_read, 16 loads, 8 barriers, waits and scalar bookkeeping
+        assert st["mfma"] == 64 and st["waterfall"] == 0 and st["readfirstlane"] == 0 and st["readlane"] == 0 and st["valu"] <= 2, (what, st)   # (one v_cmp of the group flag)
+        assert st["len"] <= 230, (what, st)          # 216 instructions this round: 64 MFMA, 48 ds_read, 16 loads, 8 barriers, waits and scalar bookkeeping

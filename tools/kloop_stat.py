@@ -32,7 +32,7 @@ def steady_loop(lines, name):
         if m and labels.get(m.group(1), k) < k:
             a = labels[m.group(1)]
             nm = sum("v_mfma" in x for x in body[a:k])
-            if nm >= 32 and (best is None or nm <= best[0]):
+            if nm >= 32 and (best is None or (nm, k - a) < (best[0], best[2] - best[1])):      # fewest MFMAs, then shortest: the innermost loop
                 best = (nm, a, k)
     if best is None:
         return {"kernel_lines": len(body), "len": 0, "mfma": 0, "waterfall": -1, "readfirstlane": -1, "readlane": -1, "salu": -1, "valu": -1}
