@@ -796,10 +796,10 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     // the same intervals on run-time flags.  NC issue 260 cycles, cluster 520, K-tile 3160 -> 2190 cycles (2048 = MFMA only).
     // ONE code path for both groups on purpose: per-group copies of the tail made the allocator spill 2400 registers at the
     // merge of the accumulator tuples.
-    // Tried on top and dropped: a PERSISTENT tile loop (one workgroup per CU; the next tile's setup and an L2 prefetch of its
-    // first K-tile issued before the epilogue): +1-3 % against the same code launched one workgroup per tile, but the state
-    // that then lives across the epilogue (kernel parameters, both tiles' descriptors) spills SGPRs into the steady loop
-    // (11 v_readlane per K-tile pair) and the kernel as a whole lost 4-9 % against this form.
+    // (Round 2 tried a persistent tile loop that kept the kernel parameters and both tiles' descriptors live across the epilogue: they
+    // spilled SGPRs into the steady loop -- 11 v_readlane per K-tile pair -- and it lost 4-9 %.  The round-5 loop above keeps nothing live:
+    // tools/kloop_stat.py on a listing shows the steady loop unchanged.  Issuing the next tile's first K-tile before the epilogue, with the
+    // strips moved out of the parity-0 stages, was measured on top of it: correct, no gain -- profiles/r05_early_ktile0_ab.txt.)
     const int ltid = tid & 255;
     const uint32_t wg_off = (uint32_t)__builtin_amdgcn_readfirstlane((wave & 3) * 1024);
     const int pc_row[4] = {wr ? 128 : 0, wr ? 192 : 64, wr ? 0 : 128, wr ? 64 : 192};  // first row of piece q in its operand
