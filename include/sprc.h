@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPRC_ABI_VERSION 5
+#define SPRC_ABI_VERSION 6
 
 enum { SPRC_OK = 0, SPRC_EINVAL = -1, SPRC_ELAUNCH = -2, SPRC_EWORKSPACE = -3, SPRC_EUNSUPPORTED = -4 };
 enum { SPRC_F32 = 0, SPRC_BF16 = 1,
@@ -82,6 +82,18 @@ typedef struct {
 int sprc_prof_enable(int on);   /* 1 = start afresh, 0 = pause (records are kept for collect), 2 = resume.  Every recorded
                                  * launch costs two stream markers (~7 us of pipeline bubble): sample steps, do not record all */
 int sprc_prof_collect(sprc_prof_entry* out /* [SPRC_K_COUNT] */);
+
+/* CU-PARTITION streams (ABI 6).  The reference runs its whole forward on one CUDA stream (blip_validate.py / utils.py:46-77: a plain loop
+ * over loader batches); on MI355X every kernel of that loop is either matrix-bound (the GEMMs' K loops, HBM idle) or memory-bound (GEMM
+ * epilogues, LayerNorm, attention: matrix pipes idle), and a kernel that owns all 256 CUs keeps them in lockstep -- the whole chip
+ * alternates between the two.  sprc_stream_create_partition(part, nparts) returns a HIP stream whose queue is restricted
+ * (hipExtStreamCreateWithCUMask) to CUs {c : (c / 8) % nparts == part} of every XCD (mask bit i = CU i/8 of XCD i%8, the KFD's layout), so
+ * that `nparts` independent batches run SIDE BY SIDE on disjoint CUs and one partition's memory bursts fall under the others' K loops.
+ * The library sizes persistent grids and its tile cost model by the CU count registered for the stream a launch goes to
+ * (sprc_stream_cus; the device's CU count for any other stream).  Caller-owned: destroy with sprc_stream_destroy. */
+int sprc_stream_create_partition(int32_t part, int32_t nparts, sprc_stream* out);
+int sprc_stream_destroy(sprc_stream s);
+int sprc_stream_cus(sprc_stream s);   /* CUs a launch on `s` can use: the partition's count, or the device's */
 
 /* amax[0] = max(amax[0], max |x|) over n bf16 values (device float, caller-initialised): fp8 scale calibration. */
 int sprc_absmax_bf16(const void* x, size_t n, float* amax, sprc_stream s);

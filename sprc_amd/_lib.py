@@ -14,7 +14,7 @@ LIB_PATH = Path(os.environ.get("SPRC_LIB_PATH") or (Path(__file__).resolve().par
 
 SPRC_F16X3 = 4                                        # storage layout of split-precision activations: rows [hi fp16 | lo e4m3 | hi e4m3] (sprc.h)
 SPRC_F32, SPRC_BF16, SPRC_F16, SPRC_FP8 = 0, 1, 2, 3   # F16: IEEE half (compute dtype since ABI 3); FP8: OCP e4m3fn operands
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_NONE, ACT_GELU, ACT_QUICKGELU = 0, 1, 2
 FP8_ALL, FP8_MLP = 1, 2                               # sprc_vit_model.fp8: qkv + fc1 + fc2, or fc1 + fc2 only, on e4m3fn operands
 DTYPES = {"fp32": SPRC_F32, "f32": SPRC_F32, "bf16": SPRC_BF16, "fp16": SPRC_F16, "f16": SPRC_F16,
@@ -116,6 +116,9 @@ SIGNATURES = {
     "sprc_last_error": (C.c_char_p, []),
     "sprc_prof_enable": (i32, [i32]),
     "sprc_prof_collect": (i32, [C.POINTER(ProfEntry)]),
+    "sprc_stream_create_partition": (i32, [i32, i32, C.POINTER(vp)]),
+    "sprc_stream_destroy": (i32, [vp]),
+    "sprc_stream_cus": (i32, [vp]),
     "sprc_cast_f32_to_bf16": (i32, [vp, vp, sz, vp]),
     "sprc_cast_f32_to_16": (i32, [vp, vp, sz, i32, vp]),
     "sprc_cast_f32_to_x3": (i32, [vp, vp, i64, i32, vp]),

@@ -35,6 +35,9 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// CUs a launch on `st` can use: the count registered by sprc_stream_create_partition for a CU-masked stream, else the device's (core.hip)
+int stream_cus(hipStream_t st);
+
 // ---- types -----------------------------------------------------------------------------------
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;

@@ -1,5 +1,6 @@
-// core.hip -- version, error reporting
+// core.hip -- version, error reporting, CU-partition streams, the per-launch profiler
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <mutex>
@@ -15,6 +16,31 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// ---- CU-partition streams (sprc.h: sprc_stream_create_partition) -------------------------------------
+static std::mutex g_part_mu;
+static std::vector<std::pair<hipStream_t, int>> g_parts;     // a handful of entries: linear search under a mutex
+static int device_cus() {
+    constexpr int MAXD = 64;
+    static int n[MAXD] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= MAXD) dev = 0;
+    if (n[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+        if (n[dev] <= 0) n[dev] = 256;
+    }
+    return n[dev];
+}
+int stream_cus(hipStream_t st) {
+    {
+        std::lock_guard<std::mutex> lk(g_part_mu);
+        for (auto& e : g_parts)
+            if (e.first == st) return e.second;
+    }
+    return device_cus();
 }
 
 // ---- profiler: event pairs recorded on the launch stream ------------------------------------------
@@ -87,6 +113,42 @@ extern "C" int sprc_prof_collect(sprc_prof_entry* out) {
     }
     return SPRC_OK;
 }
+
+extern "C" int sprc_stream_create_partition(int32_t part, int32_t nparts, sprc_stream* out) {
+    using namespace sprc;
+    SPRC_REQUIRE(out != nullptr && nparts >= 1 && nparts <= 4 && part >= 0 && part < nparts, "sprc_stream_create_partition: part %d of %d", part, nparts);
+    const int ncu = device_cus();
+    SPRC_REQUIRE(ncu % (8 * nparts) == 0 && ncu <= 1024, "sprc_stream_create_partition: %d CUs do not split into %d partitions per XCD", ncu, nparts);
+    // mask bit i = CU (i / 8) of XCD (i % 8) (the KFD distributes the bits round-robin over the XCCs, then over a chiplet's shader engines):
+    // partition `part` takes the CUs whose index inside their XCD is congruent to it -- the same share of every XCD and of every XCD's L2
+    uint32_t mask[32] = {0};
+    int n = 0;
+    const char* le = getenv("SPRC_PART_LAYOUT");     // probe switch (tools/cumask_probe.py): 0 = per-XCD shares (default), 1 = whole XCDs
+    const int layout = le ? atoi(le) : 0;            // (bit i % 8), 2 = alternate bits, 3 = contiguous bit ranges
+    for (int i = 0; i < ncu; ++i) {
+        const int owner = layout == 1 ? (i % 8) * nparts / 8 : layout == 2 ? i % nparts : layout == 3 ? (int)((int64_t)i * nparts / ncu) : (i / 8) % nparts;
+        if (owner == part) { mask[i >> 5] |= 1u << (i & 31); ++n; }
+    }
+    hipStream_t st = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask);
+    if (e != hipSuccess) { set_error("sprc_stream_create_partition: hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e)); return SPRC_EUNSUPPORTED; }
+    {
+        std::lock_guard<std::mutex> lk(g_part_mu);
+        g_parts.push_back({st, n});
+    }
+    *out = (sprc_stream)st;
+    return SPRC_OK;
+}
+extern "C" int sprc_stream_destroy(sprc_stream s) {
+    using namespace sprc;
+    {
+        std::lock_guard<std::mutex> lk(g_part_mu);
+        for (size_t i = 0; i < g_parts.size(); ++i)
+            if (g_parts[i].first == (hipStream_t)s) { g_parts.erase(g_parts.begin() + i); break; }
+    }
+    return hipStreamDestroy((hipStream_t)s) == hipSuccess ? SPRC_OK : SPRC_ELAUNCH;
+}
+extern "C" int sprc_stream_cus(sprc_stream s) { return sprc::stream_cus((hipStream_t)s); }
 
 extern "C" int sprc_version(void) { return SPRC_ABI_VERSION; }
 extern "C" const char* sprc_last_error(void) { return sprc::g_err; }

@@ -27,11 +27,11 @@ static int launch_duo(GemmParams p, hipStream_t st) {
     p.order = order;
     p.nwg0 = p.tiles_m * p.tiles_n;
     const int total = p.nwg0 * (p.dual ? 2 : 1);
-    const int slots = ((SPRC_DUO_ABL & 4) ? 1 : 2) * num_cus();
+    const int slots = ((SPRC_DUO_ABL & 4) ? 1 : 2) * num_cus(st);
     // stagger: (W + E) / 2 with W = the K loop of a tile alone on the matrix pipe (16 MFMAs x 32 cycles per K-tile) and E ~ the epilogue
     static const int sleep_env = env_int("SPRC_DUO_SLEEP", -1);
     const int nt = (int)((int64_t)p.K * 2 / DUO_KTB);
-    p.duo_sleep = sleep_env >= 0 ? sleep_env : (total > num_cus() ? nt * 256 + 4000 : 0);
+    p.duo_sleep = sleep_env >= 0 ? sleep_env : (total > num_cus(st) ? nt * 256 + 4000 : 0);
     p.duo_ctr = duo_counters();
     if (p.duo_ctr == nullptr) p.duo_sleep = 0;
     hipLaunchKernelGGL(kern, dim3(total < slots ? total : slots), dim3(256), LDS_REQ, st, p);

@@ -1076,16 +1076,7 @@ static int current_device() {
     (void)hipGetDevice(&dev);
     return dev >= 0 && dev < MAX_DEVICES ? dev : 0;
 }
-static int num_cus() {                      // per device: a process may drive several GPUs
-    static int n[MAX_DEVICES] = {0};
-    const int dev = current_device();
-    if (n[dev] == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
-        if (n[dev] <= 0) n[dev] = 256;
-    }
-    return n[dev];
-}
+static int num_cus(hipStream_t st) { return stream_cus(st); }     // the stream's CU partition, or the device (core.hip)
 // hipFuncSetAttribute applies to the function ON THE CURRENT DEVICE: opt in once per (kernel instantiation, device)
 template <typename K>
 static void optin_lds(K kern, int bytes, bool (&done)[MAX_DEVICES]) {
@@ -1164,7 +1155,7 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     // the class time of the serial, instrumented steps does not move (79.5 ms): what is saved are workgroup hand-overs while the Q-Former's
     // side-stream kernels compete for CUs (profiles/r05_persist_ab.txt)
     static const int persist = env_int("SPRC_GEMM_PERSIST", 1);
-    const int total = p.nwg0 * (p.dual ? 2 : 1), ncu = num_cus() & ~7;
+    const int total = p.nwg0 * (p.dual ? 2 : 1), ncu = num_cus(st) & ~7;
     hipLaunchKernelGGL(kern, dim3(persist && ncu > 0 && total > ncu ? ncu : total), dim3(512), LDS, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm(anti)");
     return SPRC_OK;
@@ -1217,7 +1208,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
             // C matters when a partial round of 256x256 tiles is nearly empty: the ViT GEMMs have M = 128 x 257 = 128.5 panels,
             // so N = 1408 is 774 tiles = 3.02 rounds (fc2: 732 us whole, 562 + 77 us peeled); the Q-Former Q|K|V product of
             // 233 fused queries is 531 tiles = 2.07 rounds (peel three panels: 504 tiles + 90 small ones).
-            const int ncu = num_cus();
+            const int ncu = num_cus(st);
             const int64_t tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
             // a short reduction with an fp32 + residual epilogue spends as long writing out (an HBM burst no other workgroup
             // on the CU can hide) as in its K loop: +35 % per round (14912 x 768 x 768: 46 us on 256x256, 40 on 128x128;
@@ -1318,7 +1309,7 @@ static int launch(const GemmParams& p, hipStream_t st) {
             // (the ring's 64 KB leave two workgroups per CU: only for grids that fit then -- 768 workgroups ran 5 % slower on it)
             static const int ring = env_int("SPRC_GEMM_RING", 1);
             const int64_t nwg64 = (p.dual ? 2 : 1) * (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-            return ring && nwg64 <= 2 * num_cus() ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4, MIX>(p, st)
+            return ring && nwg64 <= 2 * num_cus(st) ? launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 2, 4, MIX>(p, st)
                                                   : launch_cfg<T, OutT, ACT, MAX32, 2, 2, 1, 1, 4, 2, MIX>(p, st);
         }
     }

@@ -25,12 +25,13 @@ PLAN = [0, 0, 1, 2, 3, 4, 5, 8, 9, 10, 15, 30, 48, 49, 50, 51, 75, 120]     # pl
 
 
 def planted_images(n: int = N_GALLERY, seed: int = 5):
-    """-> iterator of (start, images[<=128, 3, 224, 224]) -- 0.8 x a mixture of 8 basis images + 0.4 x noise, one generator per batch"""
+    """-> iterator of (start, images[<=128, 3, 224, 224]) -- 0.8 x a mixture of 8 basis images + 0.4 x noise, one generator per batch
+    (noise seeds 1000 + start for the original draw, seed 5; seed * 100003 + start for any other draw)"""
     g = torch.Generator().manual_seed(seed)
     basis = torch.randn((8, 3, 224, 224), generator=g)
     coef = torch.randn((n, 8), generator=g)
     for s in range(0, n, 128):
-        gb = torch.Generator().manual_seed(1000 + s)
+        gb = torch.Generator().manual_seed(1000 + s if seed == 5 else seed * 100003 + s)
         noise = torch.randn((min(128, n - s), 3, 224, 224), generator=gb)
         yield s, torch.einsum("nk,kchw->nchw", coef[s:s + 128], basis) * 0.8 + noise * 0.4
 
@@ -105,7 +106,7 @@ def recall_report(sim_ref: torch.Tensor, sim_eng: torch.Tensor, ref: np.ndarray)
             "metrics_ref": [float(x) for x in m_ref], "metrics_eng": [float(x) for x in m_eng], "tgt": tgt, "groups": groups}
 
 
-def reference_subset_report(cfg: SprcConfig, device, dtype: str, golden_path, images=None) -> dict:
+def reference_subset_report(cfg: SprcConfig, device, dtype: str, golden_path, images=None, sd=None, keep_scores: bool = False) -> dict:
     """The bench line's `recall` object (BASELINE.json's metric: "... + Recall@1/5/10, CIRR-val"; validate_blip.py:255-285): the engine
     against scores the UNMODIFIED REFERENCE produced on its CPU fp32 path for every 22nd query of the planted CIRR-val-sized case
     (191 queries x 2297 images; the fixture is data generated by oracle/gen_c2_subset.py, read here like any dataset file).  Targets are
@@ -114,17 +115,24 @@ def reference_subset_report(cfg: SprcConfig, device, dtype: str, golden_path, im
     g = np.load(golden_path, allow_pickle=False)
     n, nq, qi = int(g["n_img"]), int(g["n_q"]), g["query_index"]
     h16 = bool(int(g["trunk_fp16"])) if "trunk_fp16" in g.files else False
-    sd = synth.make_state_dict(cfg, seed=int(g["seed"]), planted=True, trunk_fp16=h16)
+    if sd is None:                                      # (callers that hold the case's weights already pass them)
+        sd = synth.make_state_dict(cfg, seed=int(g["seed"]), planted=True, trunk_fp16=h16)
     s_eng, ref = planted_scores(cfg, sd, device, dtype, n=n, nq=nq, seed=int(g["seed"]), query_index=qi, images=images)
     assert np.array_equal(ref, g["ref_index"]), "fixture and engine disagree on the queries' reference images"
     s_ref = torch.from_numpy(g["sim"]).to(device)
     rep = recall_report(s_ref, s_eng, ref)
     o_ref, o_eng = E.topk(s_ref.contiguous(), 10)[1], E.topk(s_eng.contiguous(), 10)[1]      # the library's stable top-k (rank.hip)
     keys = ("recall_at_1", "recall_at_5", "recall_at_10")
-    return {"engine": rep["engine"], "reference": rep["reference_order"],
+    d = (s_eng - s_ref).abs().flatten().float()
+    q = torch.quantile(d[::2], torch.tensor([0.99, 0.999, 0.9999], device=d.device)).tolist()   # (torch.quantile takes < 2^24 elements)
+    out = {"engine": rep["engine"], "reference": rep["reference_order"],
             "equal_recall_at_1_5_10": all(rep["engine"][k] == rep["reference_order"][k] for k in keys),
             "equal_subset_recalls": all(rep["engine"][k] == rep["reference_order"][k] for k in ("subset_recall_at_1", "subset_recall_at_2", "subset_recall_at_3")),
             "top1_image_equal_pct": rep["top1_image_equal_pct"],
             "top10_order_equal_pct": round(100.0 * float((o_ref == o_eng).all(1).float().mean()), 3),
             "max_abs_dsim": rep["max_abs_dsim"], "rms_dsim": rep["rms_dsim"], "scores_over_1e-3": int(((s_eng - s_ref).abs() > 1e-3).sum()),
+            "dsim_quantiles_99_99.9_99.99": [float(x) for x in q],
             "scores": int(s_ref.numel()), "trunk_weights": "fp16-valued (a GPU-trained reference checkpoint: eva_vit.py:410-425)" if h16 else "fp32-valued synthetic"}
+    if keep_scores:                                    # (tests: the same engine scores against a second yardstick, without a second encode)
+        out["_s_eng"], out["_s_ref"] = s_eng, s_ref
+    return out

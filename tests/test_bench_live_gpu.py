@@ -34,6 +34,11 @@ def test_live_bench_line():
     assert 0.2 < r["frac"] < 0.6 and 0.2 < r["step_frac"] < 0.6 and r["launches"] > 300 and r["avg_launch_ms"] > 0.05
     assert r["step_frac"] == pytest.approx(r["step_alg_tflop"] / (d["ms_per_step"] * 1e-3) / r["peak"], rel=2e-3)
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None
+    # the default-on `recall` object (BASELINE.json's metric names Recall@K): the engine against the reference-scored C2 subsets.  This is the
+    # ONE live invocation that runs it (two more full-depth encodes of the 2297-image planted gallery: ~35 s); the others pass --no-recall
+    rc = d["recall"]
+    assert set(rc["fixtures_evaluated"]) == {"fp32_weights", "fp16_valued_trunk"} and rc["equal_recall_at_1_5_10"] is True
+    assert rc["fp16_valued_trunk"]["rms_dsim"] < 2e-4 and rc["fp16_valued_trunk"]["scores_over_1e-3"] <= 5
     # a dtype the reference does not benchmark with is refused by argparse, not silently accepted
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dtype", "int8"], cwd=ROOT, capture_output=True, text=True)
     assert p.returncode != 0
@@ -43,7 +48,7 @@ def test_bench_line_through_a_one_rank_rccl_group():
     """The code `bench.py --gpus N` runs on an N-GPU node -- `init_process_group("nccl", device_id=...)`, the one-rank-per-device check, both
     device-side all_gathers of the sharded ranking, the per-rank step-time record, barrier + destroy -- executed on the 1-GPU box through a
     ONE-rank RCCL group (SPRC_BENCH_FORCE_DIST=1, SPRC_DIST_ALWAYS_EXCHANGE=1).  N > 1 itself stays unmeasured until a multi-GPU box runs it."""
-    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", SPRC_BENCH_FORCE_DIST="1", SPRC_DIST_ALWAYS_EXCHANGE="1")
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-recall", SPRC_BENCH_FORCE_DIST="1", SPRC_DIST_ALWAYS_EXCHANGE="1")
     c = d["config"]
     assert c["rccl_ranks"] == 1 and c["backend"] == "rccl" and c["per_rank_ms_per_step"] == [d["ms_per_step"]]
     assert d["n_gpus"] == 1 and 500 < d["value"] < 5000

@@ -20,6 +20,10 @@ from sprc_amd import synth  # noqa: E402
 from sprc_amd.config import get_config  # noqa: E402
 
 DEV = "cuda:0"
+
+import sys as _sys, os as _os  # noqa: E402
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _cases as CASES  # noqa: E402  (session-lived full-depth state dicts: tests/_cases.py)
 B, NQ = 128, 233
 POS = [5, 77]                    # batch slots of the golden's two images
 QSLOT = [0, 100, 232]            # query slots of the golden's three queries
@@ -31,7 +35,7 @@ def setup(golden_dir):
     g = np.load(golden_dir / "full_eva.npz", allow_pickle=False)
     cfg = get_config("pretrain")
     assert int(g["vit_depth"]) == cfg.vit.depth == 39
-    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    sd = CASES.state_dict(cfg, int(g["seed"]))
     images = synth.make_images(B, seed=4321)
     images[POS] = synth.make_images(int(g["n_img"]), seed=int(g["seed"]))
     ids, mask, _ = synth.make_queries(NQ, B, seed=77)

@@ -23,11 +23,15 @@ from sprc_amd.config import get_config  # noqa: E402
 
 DEV = "cuda:0"
 
+import sys as _sys, os as _os  # noqa: E402
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _cases as CASES  # noqa: E402  (session-lived full-depth state dicts: tests/_cases.py)
+
 
 def _setup(golden_dir, name, dtype):
     g = np.load(golden_dir / name, allow_pickle=False)
     cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
-    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    sd = CASES.state_dict(cfg, int(g["seed"]))
     images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]))
     np.testing.assert_array_equal(images[:, :, 0, :4].numpy(), g["image_probe"])
     eng = E.Engine(cfg, sd, DEV, dtype=dtype, max_batch=8)

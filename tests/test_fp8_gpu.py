@@ -16,6 +16,10 @@ from sprc_amd import synth  # noqa: E402
 from sprc_amd.config import get_config  # noqa: E402
 
 DEV = "cuda:0"
+
+import sys as _sys, os as _os  # noqa: E402
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _cases as CASES  # noqa: E402  (session-lived full-depth state dicts: tests/_cases.py)
 F8 = torch.float8_e4m3fn
 
 
@@ -108,7 +112,7 @@ def test_fp8_vit_in_the_pipeline(golden_dir, name):
     asserted is the largest measured value + 50 %."""
     g = np.load(golden_dir / name, allow_pickle=False)
     cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
-    sd = synth.make_state_dict(cfg, seed=int(g["seed"]))
+    sd = CASES.state_dict(cfg, int(g["seed"]))
     images = synth.make_images(int(g["n_img"]), seed=int(g["seed"])).to(DEV)
     ref_eng = E.Engine(cfg, sd, DEV, dtype="bf16", max_batch=8)
     amax = ref_eng.calibrate_fp8(images)
@@ -133,12 +137,7 @@ def test_fp8_vit_in_the_pipeline(golden_dir, name):
 
 # ---- the structured case: what e4m3 operands do to scores that are spread over 1.0 ------------------------------------------------------
 def _planted(golden_dir, name):
-    g = np.load(golden_dir / name, allow_pickle=False)
-    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
-    sd = synth.make_state_dict(cfg, seed=int(g["seed"]), planted=True)
-    images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]), planted=True)
-    np.testing.assert_array_equal(images[:4, :, 0, :4].numpy(), g["image_probe"])
-    return g, cfg, sd, images
+    return CASES.planted_case(golden_dir, name)
 
 
 def _scores(eng, g, images, bs=32):

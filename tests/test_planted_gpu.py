@@ -23,17 +23,16 @@ from sprc_amd import synth  # noqa: E402
 from sprc_amd.config import get_config  # noqa: E402
 
 DEV = "cuda:0"
+
+import sys as _sys, os as _os  # noqa: E402
+_sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+import _cases as CASES  # noqa: E402  (session-lived full-depth state dicts: tests/_cases.py)
 K = 51
 
 
 @pytest.fixture(scope="module")
 def case(golden_dir):
-    g = np.load(golden_dir / "planted_eva.npz", allow_pickle=False)
-    cfg = get_config(str(g["model_type"]), vit_depth=int(g["vit_depth"]))
-    sd = synth.make_state_dict(cfg, seed=int(g["seed"]), planted=True)
-    images = synth.make_images(int(g["n_img"]), seed=int(g["seed"]), planted=True)
-    np.testing.assert_array_equal(images[:4, :, 0, :4].numpy(), g["image_probe"])
-    return g, cfg, sd, images
+    return CASES.planted_case(golden_dir, "planted_eva")
 
 
 def _run(case, dtype):
