@@ -70,7 +70,7 @@ static int gemm_impl(const sprc_gemm_args* a, const sprc_gemm_args* b, sprc_stre
     }
     p.scratch = reinterpret_cast<float*>(a->scratch); p.scratch_elems = (int64_t)(a->scratch_bytes / 4);
     p.w_scale = a->dtype == SPRC_FP8 ? a->w_scale : nullptr; p.a_scale = a->a_scale; p.out_scale = a->out_scale;
-    static const int dbg = env_int("SPRC_GEMM_DEBUG", 0);
+    static const int dbg = env_int("SPRC_GEMM_DEBUG", 0) | (env_int("SPRC_GEMM_DEAD", 1) ? 0 : 128);     // bit 128: dead waves multiply like live ones (A/B)
     p.debug = dbg;
     p.duo_sleep = 0; p.duo_ctr = nullptr;
     static const int epi_wide = env_int("SPRC_EPI_WIDE", 1);       // 0: 4 columns per lane in every epilogue (A/B switch, gemm_epilogue)

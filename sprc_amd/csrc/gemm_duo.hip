@@ -1,17 +1,23 @@
 // gemm_duo.hip -- instantiations and launcher of the duo GEMM kernel (gemm_duo.hpp: 256 x 128 tiles, two free-running workgroups per CU).
 // An A/B variant (SPRC_GEMM_DUO=1), OFF by default: measured 24 % behind the anti-phase kernel (negative results of round 5).
 // Only the epilogues the ViT uses are instantiated (16-bit output with / without GELU, fp32 output); anything else falls back.
+#include <mutex>
+
 #include "gemm_impl.hpp"
 
 namespace sprc {
 #include "gemm_duo.hpp"
 
-static int* duo_counters() {                // per device, zeroed once; the kernels only ever increment them
-    static int* ctr[MAX_DEVICES] = {nullptr};
+static int* duo_counters(hipStream_t st) {  // per device, zeroed once ON THE LAUNCH STREAM (ordered before the first launch that counts on them); the
+    static int* ctr[MAX_DEVICES] = {nullptr};   // kernels only ever increment them.  One allocation per device for the life of the process.
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     const int dev = current_device();
     if (ctr[dev] == nullptr) {
-        if (hipMalloc(&ctr[dev], DUO_CTRS * sizeof(int)) != hipSuccess) return nullptr;
-        (void)hipMemset(ctr[dev], 0, DUO_CTRS * sizeof(int));
+        int* c = nullptr;
+        if (hipMalloc(&c, DUO_CTRS * sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(c, 0, DUO_CTRS * sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { (void)hipFree(c); return nullptr; }
+        ctr[dev] = c;
     }
     return ctr[dev];
 }
@@ -32,7 +38,7 @@ static int launch_duo(GemmParams p, hipStream_t st) {
     static const int sleep_env = env_int("SPRC_DUO_SLEEP", -1);
     const int nt = (int)((int64_t)p.K * 2 / DUO_KTB);
     p.duo_sleep = sleep_env >= 0 ? sleep_env : (total > num_cus(st) ? nt * 256 + 4000 : 0);
-    p.duo_ctr = duo_counters();
+    p.duo_ctr = duo_counters(st);
     if (p.duo_ctr == nullptr) p.duo_sleep = 0;
     hipLaunchKernelGGL(kern, dim3(total < slots ? total : slots), dim3(256), LDS_REQ, st, p);
     SPRC_CHECK_LAUNCH("sprc_gemm(duo)");

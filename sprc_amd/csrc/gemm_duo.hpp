@@ -1,5 +1,5 @@
 // gemm_duo.hpp -- the "duo" GEMM kernel: 256 x 128 tiles on TWO free-running workgroups per CU, persistent over the tile list.
-// Included by gemm_impl.hpp (inside namespace sprc, after the shared epilogue).
+// Included by gemm_duo.hip (inside namespace sprc, after gemm_impl.hpp: it uses the shared epilogue).
 //
 // Why a second large-tile kernel.  The 256 x 256 anti-phase kernel owns a CU: while a tile sits in its prologue
 // (3.4-4.8 k cycles) or its epilogue (11 k cycles with a 16-bit output, 23-32 k with the fp32 residual stream) the matrix pipe of that CU

@@ -775,6 +775,14 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     // seen after an epilogue change: 16 loops per K-tile pair, every product 3-9 % slower).  Pin them.
     m0 = __builtin_amdgcn_readfirstlane(m0);
     n0 = __builtin_amdgcn_readfirstlane(n0);
+    // DEAD waves: a wave whose 64 columns lie at or beyond N (N = 1408 = 5.5 tiles: in every sixth-column tile of proj / fc2 the waves of column
+    // quarters 2 and 3, a twelfth of those launches' matrix work; qkv's 17th column likewise) multiplies clamped copies of row N - 1 into
+    // accumulators nobody stores.  The step is POWER-bound (a product alone on half the chip runs 1.25 x the clock: profiles/r06_cumask_probe.txt),
+    // so what those MFMAs and fragment reads cost is clock for everybody else.  A dead wave keeps its share of the staging loads, the counted
+    // waits and every barrier -- the interval skeleton below, without reads and clusters -- and skips the epilogue.  SPRC_GEMM_DEAD=0 (debug
+    // bit 128): A/B switch; same box, alternating: 87.5 / 87.9 / 88.1 ms per step with, 88.4 / 88.6 / 88.5 without (profiles/r06_dead_waves_ab.txt).
+    // (the same for a wave whose 128 ROWS lie at or beyond M: the lower half of a ragged last row panel)
+    const bool dead = !(kq->debug & 128) && (__builtin_amdgcn_readfirstlane(n0 + wc * (TN * 32)) >= kq->N || m0 + wr * (TM * 32) >= kq->M);
     f32x16 acc[TM][TN];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -994,6 +1002,43 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
         if (wr == 0) { if (n1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
         barrier();
     };
+    // the same intervals for a DEAD wave: its loads in the same order (the counted waits count the same loads), its waits, every barrier
+    auto steady_dead = [&](auto par_, int t) {
+        constexpr int PAR = decltype(par_)::value;
+        constexpr uint32_t pn = (PAR ^ 1) * PAR_BYTES;
+        const uint32_t p2 = p2_bytes[PAR];
+        const int t_p2 = t + 1 + wr;
+        piece(I0{}, pn, t + 1);                             // NC(t,0)
+        load_piece(I1{}, I0{}, pn, t + 1);
+        if (wr == 0) wait_vmcnt<3>();
+        barrier();
+        load_piece(I1{}, I1{}, pn, t + 1);                  // C(t,0): the in-cluster load
+        barrier();
+        piece(I2{}, p2, t_p2);                              // NC(t,1)
+        load_piece(I3{}, I0{}, p2, t_p2);
+        if (wr == 1) wait_vmcnt<3>();
+        barrier();
+        load_piece(I3{}, I1{}, p2, t_p2);                   // C(t,1)
+        if (wr == 0) wait_vmcnt<4>();
+        barrier();
+    };
+    auto tail_dead = [&](int t, bool n1, bool n2) {
+        const uint32_t pb = (uint32_t)(t & 1) * PAR_BYTES, pn = pb ^ PAR_BYTES;
+        const uint32_t p2 = wr ? pb : pn;
+        const int t_p2 = t + 1 + wr;
+        const bool has_p2 = wr ? n2 : n1;
+        if (n1) { piece(I0{}, pn, t + 1); load_piece(I1{}, I0{}, pn, t + 1); }
+        if (wr == 0) { if (n1) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
+        barrier();
+        if (n1) load_piece(I1{}, I1{}, pn, t + 1);
+        barrier();
+        if (has_p2) { piece(I2{}, p2, t_p2); load_piece(I3{}, I0{}, p2, t_p2); }
+        if (wr == 1) { if (n2) wait_vmcnt<3>(); else wait_vmcnt<0>(); }
+        barrier();
+        if (has_p2) load_piece(I3{}, I1{}, p2, t_p2);
+        if (wr == 0) { if (n1) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+        barrier();
+    };
     // prologue: K-tile 0 resident for everyone (each group stages its four pieces), G1's early pieces of K-tile 1 in
     // flight, G1 one interval behind
     if constexpr (STAMP) pro_ts[0] = __builtin_amdgcn_s_memtime();
@@ -1009,7 +1054,14 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     barrier();
     if (wr == 1) barrier();
     if constexpr (STAMP) tile_ts[1] = __builtin_amdgcn_s_memtime();
-    {
+    if (dead) {
+        int t = 0;
+        for (; t + 3 < nt; t += 2) {
+            steady_dead(I0{}, t);
+            steady_dead(I1{}, t + 1);
+        }
+        for (; t < nt; ++t) tail_dead(t, t + 1 < nt, t + 2 < nt);
+    } else {
         int t = 0;
         if constexpr (MIX) {                                // fp16 K-tiles (nt16 even; >= 4 e4m3 K-tiles follow, so t + 3 < nt holds throughout)
             for (; t + 1 < nt16; t += 2) {
@@ -1033,7 +1085,7 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     if (second) { pe.bias = pe.bias2; pe.c_off = pe.c_off2; }
     const bool vec_ok = (pe.N % 4 == 0) && (pe.ldc % 4 == 0) && (pe.resid == nullptr || pe.ldr % 4 == 0) &&
                         ((uintptr_t)pe.C % (4 * sizeof(OutT)) == 0) && ((uintptr_t)pe.bias % 16 == 0) && ((uintptr_t)pe.resid % 16 == 0);
-    gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(pe, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
+    if (!dead || MAX32) gemm_epilogue<T, OutT, ACT, MAX32, TM, TN>(pe, acc, m0, n0, wr, wc, r32, half, vec_ok, smem, wave);
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the epilogue's stores have left the wave
         tile_ts[3] = __builtin_amdgcn_s_memtime();
@@ -1173,11 +1225,16 @@ static bool fits_u32(const GemmParams& p) {
            p.lda_b < (1 << 24) && p.ldw_b < (1 << 24);          // the 256 x 256 kernel forms row offsets with 24-bit multiplies
 }
 
-// The vector epilogue forms a row's offset from the tile's first row with 24-bit multiplies in 32 bits: row-map stride, ldc and ldr < 2^24,
-// and the rows of one (<= 256-row) tile within 4 GiB of its first row in C and in the residual.
+// The vector epilogue forms a row's offset from the tile's first row with 24-bit multiplies in 32 bits (gemm_epilogue: mrow / __umul24): ldc and ldr
+// < 2^24; with a C row map (logical row r -> (r >> shift) * stride + (r & mask) + offset) the group index M >> shift and the stride < 2^23 (signed
+// __mul24), the map MONOTONE (stride >= rows per group: a tile's mapped rows then lie at or above its first mapped row -- the delta is an
+// unsigned 24-bit operand) and that delta -- at most (256 >> shift) + 2 groups -- < 2^24; and the rows of one (<= 256-row) tile within 4 GiB of
+// its first row in C and in the residual.  Anything else: SPRC_EUNSUPPORTED (the 64-bit path these checks replaced served any map; every
+// map the library itself builds -- the Q-Former's query / text halves, the CLS row -- passes).
 static bool epi_fits_u32(const GemmParams& p) {
     const int64_t span = p.c_shift < 0 ? 256 : (int64_t)((256 >> p.c_shift) + 2) * p.c_stride;
-    return p.ldc < (1 << 24) && p.ldr < (1 << 24) && (p.c_shift < 0 || (p.c_stride >= 0 && p.c_stride < (1 << 23))) &&
+    const bool map_ok = p.c_shift < 0 || (p.c_stride >= (1 << p.c_shift) && p.c_stride < (1 << 23) && (p.M >> p.c_shift) < (1 << 23) && span < (1 << 24));
+    return p.ldc < (1 << 24) && p.ldr < (1 << 24) && map_ok &&
            span * (p.ldc > p.ldr ? p.ldc : p.ldr) * 4 + ((int64_t)p.N + 256) * 4 < ((int64_t)1 << 32);
 }
 
@@ -1185,7 +1242,9 @@ template <typename T, typename OutT, int ACT, bool MAX32, bool MIX = false>
 static int launch(const GemmParams& p, hipStream_t st) {
     static const int forced = env_int("SPRC_GEMM_TILE", 0);
     if (!MAX32 && !epi_fits_u32(p)) {
-        set_error("sprc_gemm: ldc / ldr / row-map stride too large for the epilogue's 32-bit tile offsets (ldc=%lld ldr=%lld stride=%d)", (long long)p.ldc, (long long)p.ldr, p.c_stride);
+        set_error("sprc_gemm: ldc / ldr / C row map outside the epilogue's 32-bit tile offsets (ldc=%lld ldr=%lld; cmap: %d rows per group, stride %d -- "
+                  "the stride must be >= the rows per group and < 2^23, M / rows_per_group < 2^23)", (long long)p.ldc, (long long)p.ldr,
+                  p.c_shift < 0 ? 0 : 1 << p.c_shift, p.c_stride);
         return SPRC_EUNSUPPORTED;
     }
     const int keff = MIX ? p.K + p.k8 / 2 : p.K;                // reduction length in units of 16-bit elements (time ~ bytes of a row)

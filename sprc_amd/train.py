@@ -84,6 +84,10 @@ class _K:
     def gemm(self, x, W, bias=None, resid=None, out=None):
         if self.half:
             x, W = self.op16(x), self.op16(W)
+            # `out` is about to be overwritten (in-place accumulation: resid is out): an fp16 copy cached for it is stale from here on
+            # (nothing read one today only because every consumer of an accumulated dx went through ln_bwd first)
+            if out is not None:
+                self._c16 = [(src, c) for src, c in self._c16 if src is not out and src.data_ptr() != out.data_ptr()]
         return E.gemm(x, W, bias=bias, resid=resid, out_dtype=F32, out=out)
 
     def transpose(self, x, pad=32):

@@ -39,6 +39,10 @@ def test_live_bench_line():
     rc = d["recall"]
     assert set(rc["fixtures_evaluated"]) == {"fp32_weights", "fp16_valued_trunk"} and rc["equal_recall_at_1_5_10"] is True
     assert rc["fp16_valued_trunk"]["rms_dsim"] < 2e-4 and rc["fp16_valued_trunk"]["scores_over_1e-3"] <= 5
+    # the default-on `extra` object: config C5's per-GPU step (ViT-L, fp8 MFMA) measured by a second invocation
+    x = d["extra"]["c5_per_gpu_step"]
+    assert x["dtype"] == "fp8" and x["backbone"] == "pretrain_vitL" and x["steps"] == 20 and x["peak_tflops"] == 5000.0
+    assert x["value"] == pytest.approx(128.0 / (x["ms_per_step"] * 1e-3), rel=1e-3) and 2000 < x["value"] < 12000 and 0.1 < x["step_frac"] < 0.5
     # a dtype the reference does not benchmark with is refused by argparse, not silently accepted
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dtype", "int8"], cwd=ROOT, capture_output=True, text=True)
     assert p.returncode != 0
