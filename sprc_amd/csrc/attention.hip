@@ -822,6 +822,23 @@ __global__ __launch_bounds__(64 * NW, NBUF == 2 ? 4 : 3) void attn_dma_kernel(At
     const float inv = 1.0f / l_tot;
     constexpr int ORS = DHP * 2 + 16;
     attn_wait_vmcnt<0>();                     // the DMAs issued past the last tile still write into the ring
+    if constexpr (F16) {
+        if (p.x3 > 0) {                       // split-precision output rows (SPRC_F16X3, logical width p.x3 = H * dh): [hi fp16 | lo e4m3 | hi e4m3], straight
+            const int qo = qt * 32 + r32;     // from the registers (a lane owns one query row) -- the Q-Former's 32-query cross-attention launches
+            if (qo < p.Tq) {
+                char* orow = p.out + ((int64_t)b * p.Tq + qo) * p.ldo * 2;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d0 = dt * 32 + 8 * g + 4 * half;
+                        if (d0 < dh)
+                            store_split4(orow, p.x3, h * dh + d0, o[dt][g * 4 + 0] * inv, o[dt][g * 4 + 1] * inv, o[dt][g * 4 + 2] * inv, o[dt][g * 4 + 3] * inv);
+                    }
+            }
+            return;
+        }
+    }
     __syncthreads();                          // every wave is done reading K/V tiles
     char* so = smem + wave * (32 * ORS);
 #pragma unroll
@@ -990,6 +1007,17 @@ static int attention16(const sprc_attention_args* a, const AttnParams& p, bool t
     static const int stream = [] { const char* e = getenv("SPRC_ATTN_STREAM"); return e ? atoi(e) : 1; }();
     // SPRC_ATTN_DMA: 0 = the first streaming form (register staging), 2 / 3 = the DMA form with a ring of that many tiles
     static const int dma = [] { const char* e = getenv("SPRC_ATTN_DMA"); return e ? atoi(e) : 2; }();
+    // ONE 32-query tile over a long key axis (the Q-Former's cross-attention: 32 query tokens x 257 encoder tokens, 12 heads x 64; Qformer.py:175-281):
+    // the resident kernel stages all of K and V^T through registers into LDS with four waves and then multiplies on ONE of them (108.9 us per
+    // launch of 233 x 12 heads against a ~37-us memory floor).  The streaming DMA kernel with ONE-wave workgroups keeps a ring of 32-key tiles
+    // per workgroup (11.3 KB each), 7 / 4 workgroups per CU (ring of 2 / 3).  SPRC_ATTN_CROSS: 0 = the resident kernel (A/B), 2 (default) / 3 = ring depth.
+    // Measured (profiles/r06_cross_attn_ab.txt; launches alone, K|V rows of 9216 elements as in the model): 233 x 12 heads 88.3 -> 39.1 us (ring of 2;
+    // 45.5 with a ring of 3: fewer workgroups per CU), 128 x 12 heads 47.5 -> 21.3; the bench step 88.0 -> 87.65 ms, same box, alternating.
+    static const int cross = [] { const char* e = getenv("SPRC_ATTN_CROSS"); return e ? atoi(e) : 2; }();
+    if (cross && a->Tq <= 32 && p.Tk >= 128 && a->head_dim <= 64 && a->key_mask == nullptr && !two && a->kv_index == nullptr &&
+        (a->out_x3 ? F16 : (a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0))) {
+        return cross == 2 ? launch_dma<64, false, 1, F16, 2>(p, st) : launch_dma<64, false, 1, F16, 3>(p, st);
+    }
     if (stream && dma && !small && a->key_mask == nullptr && !two && a->kv_index == nullptr && a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0) {
         static const int nw4 = [] { const char* e = getenv("SPRC_ATTN_NW"); return e ? atoi(e) == 4 : 0; }();
         if (dma == 2 && nw4) {
