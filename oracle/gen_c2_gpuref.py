@@ -16,8 +16,9 @@ RESUMABLE and any prefix of its work is a valid fixture:
     the fixture for the gallery COLUMNS covered so far: `cols` (sorted image indices), `sim_gpuref[191, len(cols)]`, and the path's
     own distance from the CPU-fp32 golden on those columns.
 
-    python oracle/gen_c2_gpuref.py [--h16] [--threads=6] [--max-images=N]     # encode (resumes)
-    python oracle/gen_c2_gpuref.py [--h16] --finalize                         # write tests/golden/..._gpuref.npz
+    python oracle/gen_c2_gpuref.py [--h16] [--seed=7] [--threads=6] [--max-images=N]     # encode (resumes)
+    python oracle/gen_c2_gpuref.py [--h16] [--seed=7] --finalize                         # write tests/golden/..._gpuref.npz
+(--seed=S: the draw of gen_c2_subset.py --seed=S, fixture suffix _s<S>)
 """
 from __future__ import annotations
 
@@ -56,8 +57,9 @@ def image_order(need):
 class Images:
     """gen_c2_subset.py's image draw (one generator per batch of 128), with random access."""
 
-    def __init__(self):
-        g = torch.Generator().manual_seed(5)
+    def __init__(self, seed=5):
+        self.seed = seed
+        g = torch.Generator().manual_seed(seed)
         self.basis = torch.randn((8, 3, 224, 224), generator=g)
         self.coef = torch.randn((N, 8), generator=g)
         self._s, self._batch = None, None
@@ -67,7 +69,7 @@ class Images:
         for i in idx:
             s = (i // 128) * 128
             if s != self._s:
-                gb = torch.Generator().manual_seed(1000 + s)
+                gb = torch.Generator().manual_seed(1000 + s if self.seed == 5 else self.seed * 100003 + s)
                 noise = torch.randn((min(128, N - s), 3, 224, 224), generator=gb)
                 self._batch = torch.einsum("nk,kchw->nchw", self.coef[s:s + 128], self.basis) * 0.8 + noise * 0.4
                 self._s = s
@@ -77,19 +79,20 @@ class Images:
 
 def main():
     h16 = "--h16" in sys.argv
-    tag = "planted_c2_subset_eva_h16" if h16 else "planted_c2_subset_eva"
+    seed = int(_arg("seed", 5))
+    tag = ("planted_c2_subset_eva_h16" if h16 else "planted_c2_subset_eva") + ("" if seed == 5 else f"_s{seed}")
     ckpt = SCRATCH / f"{tag}_gpuref_ckpt.pt"
     SCRATCH.mkdir(exist_ok=True)
     torch.set_num_threads(int(_arg("threads", 6)))
     gold = np.load(GOLD / f"{tag}.npz")
-    ids, mask, ref = synth.make_queries(NQ, N, seed=6)
+    ids, mask, ref = synth.make_queries(NQ, N, seed=seed + 1)
     qsel = torch.arange(0, NQ, STEP)
     assert np.array_equal(qsel.numpy(), gold["query_index"]) and np.array_equal(ref[qsel].numpy(), gold["ref_index"])
     need = {int(r) for r in ref[qsel]}
     order = image_order(need)
     state = torch.load(ckpt) if ckpt.exists() else {"done": [], "feats": [], "raws": {}}
     cfg = get_config("pretrain")
-    sd = synth.make_state_dict(cfg, seed=5, planted=True, trunk_fp16=h16)
+    sd = synth.make_state_dict(cfg, seed=seed, planted=True, trunk_fp16=h16)
     model = ref_import.build_reference_model(cfg, sd, gpu_numerics=True)
 
     if "--finalize" in sys.argv:
@@ -110,7 +113,7 @@ def main():
         err = np.abs(d)
         q = np.quantile(err, [0.5, 0.99, 0.999, 0.9999])
         out = GOLD / f"{tag}_gpuref.npz"
-        np.savez_compressed(out, case=tag, model_type="pretrain", vit_depth=cfg.vit.depth, seed=5, n_img=N, n_q=NQ, query_step=STEP,
+        np.savez_compressed(out, case=tag, model_type="pretrain", vit_depth=cfg.vit.depth, seed=seed, n_img=N, n_q=NQ, query_step=STEP,
                             trunk_fp16=int(h16), cols=cols_idx.astype(np.int32), sim_gpuref=sim, max_err=np.float64(err.max()),
                             rms_err=np.float64(np.sqrt((d ** 2).mean())), quantiles=q, n_over_1e3=int((err > 1e-3).sum()))
         print(f"wrote {out}: {len(cols_idx)}/{N} gallery columns x {sim.shape[0]} queries = {sim.size} scores; reference fp16-autocast "
@@ -118,7 +121,7 @@ def main():
               f"over 1e-3: {int((err > 1e-3).sum())}")
         return
 
-    imgs = Images()
+    imgs = Images(seed)
     limit = int(_arg("max-images", N))
     t0 = time.time()
     with torch.no_grad():

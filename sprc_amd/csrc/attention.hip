@@ -607,9 +607,10 @@ __global__ __launch_bounds__(64 * NW, NBUF == 2 ? 4 : 3) void attn_dma_kernel(At
     const bool ragged = (p.Tk & 31) != 0;
 
     // ---- this lane's share of a tile's DMA: instruction q = n * NW + wave writes slots [64 q, 64 q + 64) ----
-    const __amdgpu_buffer_rsrc_t rs_k = attn_rsrc(p.k + ((int64_t)b * p.Tk * p.ldk + (int64_t)h * dh) * 2,
+    const int bk = p.idx1 ? p.idx1[b] : b;    // batch row of this sample's keys / values (kv_index: the optional reference-K|V reuse, one segment)
+    const __amdgpu_buffer_rsrc_t rs_k = attn_rsrc(p.k + ((int64_t)bk * p.Tk * p.ldk + (int64_t)h * dh) * 2,
                                                   (uint32_t)((int64_t)(p.Tk - 1) * p.ldk * 2 + dh * 2));
-    const __amdgpu_buffer_rsrc_t rs_v = attn_rsrc(p.v + ((int64_t)b * p.Tk * p.ldv + (int64_t)h * dh) * 2,
+    const __amdgpu_buffer_rsrc_t rs_v = attn_rsrc(p.v + ((int64_t)bk * p.Tk * p.ldv + (int64_t)h * dh) * 2,
                                                   (uint32_t)((int64_t)(p.Tk - 1) * p.ldv * 2 + dh * 2));
     uint32_t d_off[NI];
     bool d_ok[NI];
@@ -1014,7 +1015,8 @@ static int attention16(const sprc_attention_args* a, const AttnParams& p, bool t
     // Measured (profiles/r06_cross_attn_ab.txt; launches alone, K|V rows of 9216 elements as in the model): 233 x 12 heads 88.3 -> 39.1 us (ring of 2;
     // 45.5 with a ring of 3: fewer workgroups per CU), 128 x 12 heads 47.5 -> 21.3; the bench step 88.0 -> 87.65 ms, same box, alternating.
     static const int cross = [] { const char* e = getenv("SPRC_ATTN_CROSS"); return e ? atoi(e) : 2; }();
-    if (cross && a->Tq <= 32 && p.Tk >= 128 && a->head_dim <= 64 && a->key_mask == nullptr && !two && a->kv_index == nullptr &&
+    // (kv_index on ONE segment -- sprc_qformer_fuse_kv -- takes the same kernel: its scores stay bit-identical to the per-query projection's)
+    if (cross && a->Tq <= 32 && p.Tk >= 128 && a->head_dim <= 64 && a->key_mask == nullptr && !two &&
         (a->out_x3 ? F16 : (a->ldo % 8 == 0 && ((uintptr_t)a->out % 16) == 0))) {
         return cross == 2 ? launch_dma<64, false, 1, F16, 2>(p, st) : launch_dma<64, false, 1, F16, 3>(p, st);
     }

@@ -159,13 +159,14 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, out_dtype: int, want32=T
 
 
 def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=None, out=None,
-              k2=None, v2=None, Tk2=0, ld2=0, kv_index=None, kv2_index=None, drop=None):
+              k2=None, v2=None, Tk2=0, ld2=0, kv_index=None, kv2_index=None, drop=None, out_x3=False):
     """k2 / v2 (optional): a second key segment of Tk2 tokens appended to the key axis; kv_index / kv2_index: int32 [B] batch
-    rows of the two segments (see sprc_attention_args).  drop = (p, seed, site): training-mode dropout on the probabilities (fp32)."""
+    rows of the two segments (see sprc_attention_args).  drop = (p, seed, site): training-mode dropout on the probabilities (fp32).
+    out_x3 (fp16, Tq <= 128): the output as split-precision rows (SPRC_F16X3: an fp16 view [B * Tq, 2 H head_dim], `split_decode`)."""
     lib = L.load()
     dt = _SPRC_DT[q.dtype]
     if out is None:
-        out = torch.empty((B * Tq, H * head_dim), dtype=q.dtype, device=q.device)
+        out = torch.empty((B * Tq, (2 if out_x3 else 1) * H * head_dim), dtype=q.dtype, device=q.device)
     a = L.AttentionArgs()
     a.B, a.H, a.Tq, a.Tk, a.head_dim, a.dtype = B, H, Tq, Tk, head_dim, dt
     a.q, a.ldq, a.k, a.ldk, a.v, a.ldv = q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv
@@ -176,6 +177,7 @@ def attention(q, k, v, B, H, Tq, Tk, head_dim, ldq, ldk, ldv, scale, key_mask=No
     a.kv_index, a.kv2_index = _ptr(kv_index), _ptr(kv2_index)
     if drop is not None:
         a.drop_p, a.drop_seed, a.drop_site = drop
+    a.out_x3 = int(bool(out_x3))
     L.check(lib.sprc_attention(C.byref(a), _stream()), "sprc_attention")
     return out
 

@@ -38,7 +38,7 @@ def test_live_bench_line():
     # ONE live invocation that runs it (two more full-depth encodes of the 2297-image planted gallery: ~35 s); the others pass --no-recall
     rc = d["recall"]
     assert set(rc["fixtures_evaluated"]) == {"fp32_weights", "fp16_valued_trunk"} and rc["equal_recall_at_1_5_10"] is True
-    assert rc["fp16_valued_trunk"]["rms_dsim"] < 2e-4 and rc["fp16_valued_trunk"]["scores_over_1e-3"] <= 5
+    assert rc["fp16_valued_trunk"]["rms_dsim"] < 2e-4 and rc["fp16_valued_trunk"]["scores_over_1e-3"] < 1e-3 * rc["fp16_valued_trunk"]["scores"]
     # the default-on `extra` object: config C5's per-GPU step (ViT-L, fp8 MFMA) measured by a second invocation
     x = d["extra"]["c5_per_gpu_step"]
     assert x["dtype"] == "fp8" and x["backbone"] == "pretrain_vitL" and x["steps"] == 20 and x["peak_tflops"] == 5000.0

@@ -562,3 +562,66 @@ def test_attention_two_key_segments(dtype):
                       kv_index=ia.to(DEV), kv2_index=ib.to(DEV)).cpu()
     tol = 2e-2 if dtype == "bf16" else 2e-5
     torch.testing.assert_close(out.float().double(), ref, atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_attention_one_query_tile_over_a_long_key_axis(dtype):
+    """The Q-Former's cross-attention shape (Qformer.py:175-281: 32 query tokens x 257 encoder tokens, 12 heads x 64, no key mask) runs on
+    ONE-WAVE workgroups of the streaming DMA kernel (round 6): every kind of last key tile, fewer than 32 queries, head dims below 64, K|V
+    read out of wider token rows (the model's [B * 257, 9216] layout) -- and, fp16, the split-precision output rows (SPRC_F16X3) written
+    straight from the registers: their hi segment equals the plain output's bits, lo / e4m3 segments decode to the same values."""
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    for B, H, Tq, Tk, dh in ((2, 12, 32, 257, 64), (3, 5, 32, 128, 64), (2, 3, 17, 129, 40), (1, 4, 1, 300, 64), (2, 2, 32, 260, 8), (2, 12, 32, 288, 64)):
+        D = H * dh
+        ld = 3 * D + 16                                      # K at column 0, V at column D + 8 of a wider row
+        q = _rand((B * Tq, D), 1200 + Tk).to(tdt).to(DEV)
+        kv = _rand((B * Tk, ld), 1300 + Tk).to(tdt).to(DEV)
+        k, v = kv[:, :D], kv[:, D + 8:2 * D + 8]
+        scale = dh ** -0.5
+        ref = _attn_ref(q.cpu().float().view(B, Tq, H, dh).transpose(1, 2), k.cpu().float().reshape(B, Tk, H, dh).transpose(1, 2),
+                        v.cpu().float().reshape(B, Tk, H, dh).transpose(1, 2), scale).transpose(1, 2).reshape(B * Tq, D)
+        out = E.attention(q, k, v, B, H, Tq, Tk, dh, D, ld, ld, scale)
+        tol = 2e-2 if dtype == "bf16" else 3e-3
+        torch.testing.assert_close(out.cpu().float().double(), ref, atol=tol, rtol=tol, msg=lambda m: f"B={B} H={H} Tq={Tq} Tk={Tk} dh={dh} {dtype}\n{m}")
+        if dtype == "fp16" and D % 4 == 0:
+            rows = E.attention(q, k, v, B, H, Tq, Tk, dh, D, ld, ld, scale, out_x3=True)
+            hi, lo8, hi8 = E.split_decode(rows, D)
+            torch.testing.assert_close(hi.float(), out.float(), atol=0, rtol=2.0 ** -10)     # (one ulp: the two epilogues may contract o * inv differently)
+            assert float((hi != out).float().mean()) < 1e-2, (Tq, Tk, dh)
+            # lo: the fp16 rounding residual of the fp32 value (<= 2^-11 relative, stored to 3 mantissa bits); hi8: the value itself in e4m3
+            assert float(lo8.abs().max()) <= float(out.float().abs().max()) * 2.0 ** -10
+            torch.testing.assert_close(hi8, out.float(), atol=2.0 ** -9, rtol=2.0 ** -3)
+
+
+def test_cu_partition_streams():
+    """sprc_stream_create_partition (ABI 6): CU-masked streams over disjoint shares of every XCD.  A product launched on a partition sizes
+    its persistent grid by the partition's CU count and gives the bits of the same product on the whole chip; two partitions run side by
+    side (fork / join on a NON-blocking stream: the masked streams are blocking ones, and any null-stream operation serialises them)."""
+    import ctypes as C
+    lib = L.load()
+    main = torch.cuda.Stream(device=DEV)
+    full = lib.sprc_stream_cus(None)
+    assert full >= 64 and full % 16 == 0
+    handles = []
+    for i in range(2):
+        h = C.c_void_p()
+        L.check(lib.sprc_stream_create_partition(i, 2, C.byref(h)), "sprc_stream_create_partition")
+        assert lib.sprc_stream_cus(h) == full // 2
+        handles.append(h)
+    assert lib.sprc_stream_create_partition(2, 2, C.byref(C.c_void_p())) != 0          # part out of range
+    A, W = _rand((4096 + 40, 1408), 31).to(torch.float16).to(DEV), _rand((1408 + 128, 1408), 32).to(torch.float16).to(DEV)
+    with torch.cuda.stream(main):
+        want = E.gemm(A, W)
+        outs = []
+        for h in handles:
+            st = torch.cuda.ExternalStream(h.value, device=DEV)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                outs.append(E.gemm(A, W))
+            main.wait_stream(st)
+    torch.cuda.synchronize()
+    for o in outs:                                          # (the tile choice follows the CU count: same reduction order per element, not asserted bit for bit)
+        torch.testing.assert_close(o.float(), want.float(), atol=2e-2, rtol=2e-3)
+    for h in handles:
+        L.check(lib.sprc_stream_destroy(h), "sprc_stream_destroy")
+        assert lib.sprc_stream_cus(h) == full                                            # no longer registered
