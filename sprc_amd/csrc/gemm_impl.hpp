@@ -216,8 +216,20 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 // volatile asm: as a pure intrinsic hipcc SINKS the MFMAs of a whole K-tile pair to the loop latch (legal, and fatal for the
 // interval structure); the statement stays where it is written.  Callers keep >= 8 other MFMAs between two uses of one
 // accumulator (no hazard nops are inserted for inline asm).
+// SPRC_MX_FP6_TIMING (variant builds only, tools/r06_ab_fp6.sh; WRONG results): the correction segments' MFMAs issued in the fp6 (e2m3) format on
+// the first 24 of the 32 operand bytes -- half the passes of the e4m3 form -- to MEASURE what fp6 correction segments would buy before any
+// producer writes them.
+#ifndef SPRC_MX_FP6_TIMING
+#define SPRC_MX_FP6_TIMING 0
+#endif
 __device__ __forceinline__ f32x16 mfma_mx8(const i32x8& bb, const i32x8& aa, f32x16 c, int sc = MX_UNIT_SCALE) {
     // sc: the E8M0 block scale of BOTH operands in every byte (0x7f = 2^0: unit scales; MX_SPLIT_SCALE for the split-precision segments)
+    if constexpr (SPRC_MX_FP6_TIMING != 0) {
+        typedef __attribute__((ext_vector_type(6))) int i32x6;
+        const i32x6 b6 = {bb[0], bb[1], bb[2], bb[3], bb[4], bb[5]}, a6 = {aa[0], aa[1], aa[2], aa[3], aa[4], aa[5]};
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:2 blgp:2" : "+v"(c) : "v"(b6), "v"(a6), "v"(sc));
+        return c;
+    }
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]" : "+v"(c) : "v"(bb), "v"(aa), "v"(sc));
     return c;
 }
@@ -233,7 +245,8 @@ template <int SC = MX_UNIT_SCALE>
 __device__ __forceinline__ f32x16 mfma_mx(const u32x4& b0, const u32x4& b1, const u32x4& a0, const u32x4& a1, f32x16 c) {
     const i32x8 bb = {(int)b0[0], (int)b0[1], (int)b0[2], (int)b0[3], (int)b1[0], (int)b1[1], (int)b1[2], (int)b1[3]};
     const i32x8 aa = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bb, aa, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, SC, 0, SC);
+    constexpr int FMT = SPRC_MX_FP6_TIMING != 0 ? 2 /* e2m3: timing variant, see mfma_mx8 */ : 0 /* e4m3 */;
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bb, aa, c, FMT, FMT, 0, SC, 0, SC);
 }
 
 // One K-tile of the 128x128 kernel on MX fp8: two K = 64 steps, each from a PAIR of 16-B fragments per operand row-tile; the
