@@ -85,6 +85,8 @@ def parse():
                     "recalls of the benchmarked engine on the planted-structure CIRR-val-sized case next to the UNMODIFIED REFERENCE's own scores for "
                     "every 22nd query of that case -- 191 queries x 2297 images, tests/golden/planted_c2_subset_eva*.npz; ~40 s; synthetic weights: "
                     "the real checkpoint is a network fetch)")
+    ap.add_argument("--no-power", action="store_true", help="skip roofline.power (socket power + shader clock from rocm-smi over ~6 s of extra un-timed steps "
+                    "after the timed region, N = 1)")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (default ON for the default N = 1 fp16 ViT-g line: config C5's per-GPU encode step -- "
                     "ViT-L backbone, fp8 MFMA, 20 timed steps -- measured by a second invocation of this script after the timed region, ~15 s)")
     ap.add_argument("--recall", action="store_true", help="(accepted for compatibility: the recall object is on by default)")
@@ -266,6 +268,50 @@ def c5_slice(a, dev, rank, world):
     print(json.dumps(out), flush=True)
 
 
+def power_sample(run_steps, seconds: float = 6.0):
+    """Socket power and shader clock (rocm-smi, ~4 Hz) while `run_steps(n)` repeats the benchmarked step AFTER the timed region: the
+    2.5 PFLOP/s the roofline prices against is the 2.4-GHz figure, and under this step the part sits at its power cap well below that clock
+    (1400 W, 1.55 GHz under the GEMM alone).  None when rocm-smi is missing or prints something else."""
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+    if exe is None:
+        return None
+    stop, acc = threading.Event(), []
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                d = json.loads(subprocess.run([exe, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout)
+                c = d[sorted(k for k in d if k.startswith("card"))[0]]
+                pw = next((float(v) for k, v in c.items() if "Power" in k and "(W)" in k and v not in ("N/A", "")), None)
+                ck = next((v for k, v in c.items() if k.startswith("sclk clock speed")), None)
+                mhz = float("".join(ch for ch in ck if ch.isdigit() or ch == ".")) if ck else None
+                if pw is not None and mhz is not None:
+                    acc.append((pw, mhz))
+            except Exception:
+                pass
+            stop.wait(0.2)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    t0, n = time.perf_counter(), 0
+    run_steps(3)                                             # the clock settles within a few steps
+    th.start()
+    while time.perf_counter() - t0 < seconds:
+        run_steps(4)
+        n += 4
+    stop.set()
+    th.join(timeout=30)
+    acc = acc[1:]                                            # (the first sample straddles the start)
+    if len(acc) < 3:
+        return None
+    pw, ck = [x[0] for x in acc], [x[1] for x in acc]
+    return {"socket_w_mean": round(sum(pw) / len(pw), 1), "socket_w_max": round(max(pw), 1), "sclk_mhz_mean": round(sum(ck) / len(ck), 1),
+            "samples": len(acc), "steps_run": n,
+            "source": "rocm-smi --showpower --showclocks, ~4 Hz, over extra un-timed steps of the same pipelined schedule after the timed region"}
+
+
 def c5_extra(dev) -> dict:
     """BASELINE config C5's per-GPU number on the box that measures the headline: the C2-shaped step on the ViT-L backbone with
     the ViT's qkv / fc1 / fc2 products on e4m3 operands (fp8 MFMA), 20 timed steps, by a second invocation of this script (its own process: its own
@@ -273,7 +319,7 @@ def c5_extra(dev) -> dict:
     import subprocess
     torch.cuda.synchronize()
     cmd = [sys.executable, os.path.abspath(__file__), "--backbone", "pretrain_vitL", "--dtype", "fp8", "--steps", "20", "--warmup", "3",
-           "--no-recall", "--no-cpu-baseline", "--no-extra", "--prof-every", "0"]
+           "--no-recall", "--no-cpu-baseline", "--no-extra", "--no-power", "--prof-every", "0"]
     try:
         p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
         line = next(ln for ln in p.stdout.splitlines() if ln.startswith("{"))
@@ -497,6 +543,17 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     n_prof = max(n_prof, 1)
+    power = None
+    if world == 1 and not use_dist and not a.no_power:
+        def more(k):
+            for i in range(0, k, G):
+                (group_pipelined if pipe else group)(a.warmup + a.steps + i, min(G, k - i))
+            drain()
+            torch.cuda.synchronize()
+        try:
+            power = power_sample(more)
+        except Exception:
+            power = None
     prof = (L.ProfEntry * len(L.K_CLASSES))()
     L.check(lib.sprc_prof_collect(prof), "sprc_prof_collect")
     lib.sprc_prof_enable(0)
@@ -577,7 +634,12 @@ def main():
                          # executed on top of it (split-precision products reduce over 3 K, the patch embedding over zero padding)
                          "class_alg_tflop_per_step": round(pe.flops / n_prof * 1e-12, 3),
                          "executed_tflop_per_step": round(pe.exec_flops / n_prof * 1e-12, 3),
-                         "executed_tflops": round(pe.exec_flops / max(pe.busy_ms, 1e-9) / 1e9, 1)},
+                         "executed_tflops": round(pe.exec_flops / max(pe.busy_ms, 1e-9) / 1e9, 1),
+                         # the peak above is the 2.4-GHz figure; `power` says what clock the part's power cap allows under THIS step, and
+                         # what the matrix pipes could deliver at that clock (peak x sclk / 2400 MHz)
+                         "power": (dict(power, peak_at_sclk_tflops=round(peak * power["sclk_mhz_mean"] / 2400.0, 1),
+                                        step_frac_of_peak_at_sclk=round(step_tflop / (dt / a.steps) / (peak * power["sclk_mhz_mean"] / 2400.0), 4))
+                                   if power else None)},
             "kernels": kernels,
         }
         if not a.no_recall and world == 1 and a.backbone == "pretrain" and a.dtype in ("fp16", "bf16", "fp32"):

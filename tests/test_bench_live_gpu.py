@@ -39,6 +39,10 @@ def test_live_bench_line():
     rc = d["recall"]
     assert set(rc["fixtures_evaluated"]) == {"fp32_weights", "fp16_valued_trunk"} and rc["equal_recall_at_1_5_10"] is True
     assert rc["fp16_valued_trunk"]["rms_dsim"] < 2e-4 and rc["fp16_valued_trunk"]["scores_over_1e-3"] < 1e-3 * rc["fp16_valued_trunk"]["scores"]
+    # roofline.power: rocm-smi over extra un-timed steps -- the part sits at its power cap, far below the 2.4 GHz the 2.5 PF peak assumes
+    pw = r["power"]
+    assert pw is not None and pw["samples"] >= 3 and 800 < pw["socket_w_mean"] <= 1500 and 1000 < pw["sclk_mhz_mean"] < 2450
+    assert pw["peak_at_sclk_tflops"] == pytest.approx(2500.0 * pw["sclk_mhz_mean"] / 2400.0, rel=1e-3) and r["step_frac"] < pw["step_frac_of_peak_at_sclk"] < 1.0
     # the default-on `extra` object: config C5's per-GPU step (ViT-L, fp8 MFMA) measured by a second invocation
     x = d["extra"]["c5_per_gpu_step"]
     assert x["dtype"] == "fp8" and x["backbone"] == "pretrain_vitL" and x["steps"] == 20 and x["peak_tflops"] == 5000.0
@@ -52,7 +56,7 @@ def test_bench_line_through_a_one_rank_rccl_group():
     """The code `bench.py --gpus N` runs on an N-GPU node -- `init_process_group("nccl", device_id=...)`, the one-rank-per-device check, both
     device-side all_gathers of the sharded ranking, the per-rank step-time record, barrier + destroy -- executed on the 1-GPU box through a
     ONE-rank RCCL group (SPRC_BENCH_FORCE_DIST=1, SPRC_DIST_ALWAYS_EXCHANGE=1).  N > 1 itself stays unmeasured until a multi-GPU box runs it."""
-    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-recall", SPRC_BENCH_FORCE_DIST="1", SPRC_DIST_ALWAYS_EXCHANGE="1")
+    d = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-recall", "--no-power", SPRC_BENCH_FORCE_DIST="1", SPRC_DIST_ALWAYS_EXCHANGE="1")
     c = d["config"]
     assert c["rccl_ranks"] == 1 and c["backend"] == "rccl" and c["per_rank_ms_per_step"] == [d["ms_per_step"]]
     assert d["n_gpus"] == 1 and 500 < d["value"] < 5000
@@ -62,7 +66,7 @@ def test_bench_line_with_grouped_qformer_stage():
     """`--qf-group G`: the ViT runs per step, the Q-Former stage (gallery-side pass, fusion, ranking) once per G steps on their G x 128 images and
     G x 233 queries, a last partial group flushed inside the timed region: the line keeps the contract (value from the step time, per-step class
     figures from the instrumented group)."""
-    d = _run("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-recall", "--qf-group", "2")
+    d = _run("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-recall", "--no-power", "--qf-group", "2")
     assert d["config"]["qformer_group"] == 2 and d["steps"] == 5
     assert d["value"] == pytest.approx(128.0 / (d["ms_per_step"] * 1e-3), rel=1e-3) and 500 < d["value"] < 5000
     r = d["roofline"]
