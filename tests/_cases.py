@@ -79,3 +79,11 @@ def planted_case(golden_dir, case: str):
     img = images(int(g["n_img"]), int(g["seed"]), planted=True)
     np.testing.assert_array_equal(img[:4, :, 0, :4].numpy(), g["image_probe"])
     return g, cfg, sd, img
+
+
+def stop_prefetch() -> None:
+    """drop the draws that have not started (session end: a subset run must not wait for dicts nobody will use)"""
+    global _POOL
+    if _POOL is not None:
+        _POOL.shutdown(wait=False, cancel_futures=True)
+        _POOL = None

@@ -41,3 +41,9 @@ def pytest_runtest_setup(item):
         _PREFETCH["started"] = True
         import _cases
         _cases.prefetch(GOLDEN)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _PREFETCH["started"]:
+        import _cases
+        _cases.stop_prefetch()
