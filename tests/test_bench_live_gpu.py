@@ -40,9 +40,12 @@ def test_live_bench_line():
     assert set(rc["fixtures_evaluated"]) == {"fp32_weights", "fp16_valued_trunk"} and rc["equal_recall_at_1_5_10"] is True
     assert rc["fp16_valued_trunk"]["rms_dsim"] < 2e-4 and rc["fp16_valued_trunk"]["scores_over_1e-3"] < 1e-3 * rc["fp16_valued_trunk"]["scores"]
     # roofline.power: rocm-smi over extra un-timed steps -- the part sits at its power cap, far below the 2.4 GHz the 2.5 PF peak assumes
-    pw = r["power"]
-    assert pw is not None and pw["samples"] >= 3 and 800 < pw["socket_w_mean"] <= 1500 and 1000 < pw["sclk_mhz_mean"] < 2450
-    assert pw["peak_at_sclk_tflops"] == pytest.approx(2500.0 * pw["sclk_mhz_mean"] / 2400.0, rel=1e-3) and r["step_frac"] < pw["step_frac_of_peak_at_sclk"] < 1.0
+    pw = r["power"]                       # (None where rocm-smi is missing or prints something else: the line must not depend on it)
+    if pw is not None:
+        assert pw["samples"] >= 3 and 800 < pw["socket_w_mean"] <= 1500 and 1000 < pw["sclk_mhz_mean"] < 2450
+        assert pw["peak_at_sclk_tflops"] == pytest.approx(2500.0 * pw["sclk_mhz_mean"] / 2400.0, rel=1e-3) and r["step_frac"] < pw["step_frac_of_peak_at_sclk"] < 1.0
+    else:
+        print("\n[live bench line] roofline.power is null on this box (rocm-smi unavailable)")
     # the default-on `extra` object: config C5's per-GPU step (ViT-L, fp8 MFMA) measured by a second invocation
     x = d["extra"]["c5_per_gpu_step"]
     assert x["dtype"] == "fp8" and x["backbone"] == "pretrain_vitL" and x["steps"] == 20 and x["peak_tflops"] == 5000.0
