@@ -158,12 +158,13 @@ def _c4_model(case, depth):
 def test_c4_sizes_eight_ranks_sharing_the_gpu_equal_the_single_process_submission():
     """BASELINE config C4 at its REAL sizes -- CIRR test1: 2 316 gallery images, 4 148 composed queries, the gallery in 8 shards -- through
     `generate_cirr_test_dicts_sharded` (cirr_test_submission.py:61-132) with eight ranks that share the box's one GPU (gloo staging: a
-    plumbing run, not a scaling number; ViT truncated to one block to bound time, the full Q-Former): ragged shards (2316 = 8 x 289 + 4),
+    plumbing run, not a scaling number; the full-depth ViT-g and the full Q-Former, exact-fp32 engine so that the shards' scores are the
+    single process's bit for bit): ragged shards (2316 = 8 x 289 + 4),
     owner-routed fusion with unequal per-rank query counts, both exchanges, the 8 x 51-candidate merge.  The two submission dicts (top-50
     names, subset top-3) of every rank must equal the single-process harness's, entry for entry."""
     from sprc_amd import harness as H
     import time
-    world, depth = 8, 1
+    world, depth = 8, int(os.environ.get("SPRC_C4_TEST_DEPTH", "39"))      # the FULL 39-block ViT-g since round 6 (rounds 2-5 truncated it to one block)
     t0 = time.time()
     with mp.Manager() as mgr:
         out = mgr.dict()
