@@ -75,3 +75,16 @@ def test_bench_line_with_grouped_qformer_stage():
     r = d["roofline"]
     assert 0.2 < r["frac"] < 0.6 and r["traffic"] is None                 # the committed counter profile belongs to the ungrouped command
     assert d["kernels"]["gemm_bf16"]["launches_per_step"] > 150
+
+
+def test_bench_line_of_the_c5_slice():
+    """Config C5's per-GPU share (synthetic 1 M-image gallery x 10 k composed queries, ViT-L backbone, fp8 MFMA, 8 GPUs): ONE GPU's
+    125 000-image shard -- ViT-L encode steps on e4m3 operands timed live, then the shard's fusion and bf16 ranking passes at their real sizes
+    (the full 1 M x 10 k ranking in 8 logical shards is tests/test_fullsize_gpu.py).  The 8-GPU run itself needs a multi-GPU box."""
+    d = _run("--workload", "c5-slice", "--backbone", "pretrain_vitL", "--dtype", "fp8", "--steps", "20", "--warmup", "3")
+    c = d["config"]
+    assert d["dtype"] == "fp8" and c["backbone"] == "pretrain_vitL" and c["shard"] == 125000 and c["queries"] == 10000 and c["batch"] == 128
+    assert d["steps"] == 20 and d["n_gpus"] == 1 and "C5 slice" in c["workload"] and c["rank_dtype"] == "bf16" and c["topk"] == 51
+    assert 3000 < d["value"] < 12000 and 10 < d["ms_per_step"] < 45 and 20 < c["fuse_rank_ms"] < 500
+    r = d["roofline"]
+    assert r["peak"] == 5000.0 and 0.1 < r["frac"] < 0.5
