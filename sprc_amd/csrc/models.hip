@@ -181,8 +181,18 @@ static X3Layouts x3_layouts(int cm) {
 // MFMA: products to ~2^-16); the others reduce over the hi segment only (packed weight rows are then read through their pitch).  The three groups
 // of activation buffers (LayerNorm copies, attention outputs, FFN hidden) are split only when one of their consumers is in cm
 // (x3_layouts).  q / k / v and the attention probabilities stay plain fp16.
+// need_n > 0: only rows [need_lo, need_lo + need_n) of every sample are read after the stack (need_n a power of two; either a subset
+// of the query rows when `kv` is given, or -- without `kv` -- any run of rows): the LAST layer then runs everything behind its
+// self-attention (output projection, cross-attention, FFNs, LayerNorms) on those rows alone.  The other rows of x32 / x16 keep the
+// previous layer's values.  Pass 1 of the fusion is read on its 32 query rows (align_prompt.py:341-346), pass 2 on the one [CLS] row
+// (:348-350), the text passes on row 0, the ITM pass on its query rows: work nobody reads, 0.5 ms of kernel time per bench step.
+static bool qf_dead_rows_enabled() {
+    static const int on = [] { const char* e = getenv("SPRC_QF_DEAD"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int B, int S, const KvSrc* kvs,
-                    const float* mask, float* x32, void* x16, int cm) {
+                    const float* mask, float* x32, void* x16, int cm, int need_lo = 0, int need_n = 0) {
     const bool with_enc = kvs != nullptr;
     const int dt = m->dtype, Hd = m->hidden, H = m->heads, dh = m->head_dim, F = m->ffn, Lq = m->num_query;
     const X3Layouts lay = x3_layouts(cm);
@@ -215,12 +225,37 @@ static int qf_stack(const sprc_qformer_model* m, hipStream_t st, QfBufs& q, int 
                  nullptr, wld(kind, width), k8of(kind, width)));
         return lnorm(st, adt, rows, Hd, q.t32, lw, lb, m->ln_eps, o32, o16, cmap);
     };
+    const bool prune = qf_dead_rows_enabled() && !fuse_add && need_n > 0 && need_n < S && (need_n & (need_n - 1)) == 0 &&
+                       (with_enc ? (split && need_lo == 0 && need_n == Lq) : true);
     for (int l = 0; l < m->n_layers; ++l) {
         const sprc_qf_layer& L = m->layers[l];
         // self-attention over all S rows
         RUN(lin(SPRC_X3_QKV, R, 3 * Hd, Hd, x16, KH, L.qkv, dt, q.qkv, 3 * Hd, SPRC_ACT_NONE, ID_MAP, ID_MAP));
         RUN(attn(st, dt, B, H, S, S, dh, q.qkv, 3 * Hd, (char*)q.qkv + Hd * es, 3 * Hd, (char*)q.qkv + 2 * Hd * es, 3 * Hd,
                  q.ctx, KC, mask, sc, nullptr, 0, lay.ctx));
+        if (prune && l == m->n_layers - 1) {
+            // last layer, rows nobody reads dropped: nmap = the needed rows of every sample
+            const sprc_rowmap nmap = {need_n, S, need_lo};
+            const int Rn = B * need_n;
+            RUN(branch(SPRC_X3_ATTN_OUT, Rn, Hd, KC, q.ctx, L.attn_out, x32, L.attn_ln_w, L.attn_ln_b, q.a32, q.a16, nmap, nmap));
+            if (with_enc) {                       // the needed rows are the query rows: cross-attention + query FFN as in any layer, no text FFN
+                if (L.has_cross) {
+                    RUN(lin(SPRC_X3_CROSS_Q, Rn, Hd, Hd, q.a16, KH, L.cq, dt, q.cq, Hd, SPRC_ACT_NONE, nmap, ID_MAP));
+                    const size_t off = (size_t)L.cross_index * 2 * Hd * es;
+                    const char* kp = (const char*)kvs->a + off;
+                    const bool plain = kvs->b == nullptr && kvs->ia == nullptr;
+                    RUN(attn(st, dt, B, H, Lq, kvs->Ta, dh, q.cq, Hd, kp, kvs->ld, kp + Hd * es, kvs->ld, q.ctx, KC, nullptr, sc,
+                             plain ? nullptr : kvs, off, lay.ctx));
+                    RUN(branch(SPRC_X3_CROSS_OUT, Rn, Hd, KC, q.ctx, L.cross_out, q.a32, L.cross_ln_w, L.cross_ln_b, q.a32, q.a16, ID_MAP, nmap));
+                }
+                RUN(lin(SPRC_X3_FFN_IN, Rn, F, Hd, q.a16, KH, L.ffn_q_in, fdt, q.ffn, KF, SPRC_ACT_GELU, nmap, ID_MAP));
+                RUN(branch(SPRC_X3_FFN_OUT, Rn, F, KF, q.ffn, L.ffn_q_out, q.a32, L.ffn_q_ln_w, L.ffn_q_ln_b, x32, x16, ID_MAP, nmap));
+            } else {
+                RUN(lin(SPRC_X3_FFN_IN, Rn, F, Hd, q.a16, KH, L.ffn_t_in, fdt, q.ffn, KF, SPRC_ACT_GELU, nmap, ID_MAP));
+                RUN(branch(SPRC_X3_FFN_OUT, Rn, F, KF, q.ffn, L.ffn_t_out, q.a32, L.ffn_t_ln_w, L.ffn_t_ln_b, x32, x16, ID_MAP, nmap));
+            }
+            break;
+        }
         RUN(branch(SPRC_X3_ATTN_OUT, R, Hd, KC, q.ctx, L.attn_out, x32, L.attn_ln_w, L.attn_ln_b, q.a32, q.a16, ID_MAP, ID_MAP));
         if (with_enc) {
             const sprc_rowmap rq = split ? qmap : ID_MAP;
@@ -540,14 +575,14 @@ static int qformer_fuse_impl(const sprc_qformer_model* m, const float* ref_embed
     e.query_embeds = m->query_tokens; e.q_bstride = 0;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, &kvs, q.mask, q.h32, q.h16, cm));
+    RUN(qf_stack(m, st, q, B, S, &kvs, q.mask, q.h32, q.h16, cm, 0, Lq));       // read: the query rows
     if (loss_align != nullptr)                  // training: mse(mean fused query token, mean prompt token)  (align_prompt.py:192-193)
         RUN(sprc_align_mse(q.h32, (int64_t)S * Hd, Lq, Hd, prompt_tokens, B, loss_align, st));
     // pass 2: pass-1 query rows as query_embeds (re-LayerNormed by the embedding LN), no image (:341-346)
     e.query_embeds = q.h32; e.q_bstride = (int64_t)S * Hd;
     e.y32 = q.g32; e.y16 = q.g16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.g32, q.g16, cm));
+    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.g32, q.g16, cm, Lq, 1));     // read: the [CLS] row
     // fusion = normalize(text_proj(pass2[:, 32, :]))  (:348-350): row Lq of every sample
     const sprc_rowmap cls_row = {1, S, Lq};
     RUN(head(m, st, cm, B, q.g16, m->text_proj, q.proj, cls_row));
@@ -603,7 +638,7 @@ extern "C" int sprc_qformer_text_only(const sprc_qformer_model* m, const float* 
     e.query_embeds = prompt_tokens; e.q_bstride = 0;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.h32, q.h16, cm));
+    RUN(qf_stack(m, st, q, B, S, nullptr, q.mask, q.h32, q.h16, cm, 0, 1));
     const sprc_rowmap row0 = {1, S, 0};                                      // last_hidden_state[:, 0, :]  (:177-179)
     RUN(head(m, st, cm, B, q.h16, m->text_proj, q.proj, row0));
     return sprc_l2norm_rows(q.proj, m->embed_dim, feat, feat16, m->embed_dim, B, m->embed_dim, dt, st);
@@ -631,7 +666,7 @@ extern "C" int sprc_qformer_text(const sprc_qformer_model* m, const int64_t* inp
     e.gamma = m->emb_ln_w; e.beta = m->emb_ln_b; e.eps = m->ln_eps;
     e.y32 = q.h32; e.y16 = q.h16;
     RUN(sprc_qformer_embed(&e, st));
-    RUN(qf_stack(m, st, q, B, Lt, nullptr, q.mask, q.h32, q.h16, cm));
+    RUN(qf_stack(m, st, q, B, Lt, nullptr, q.mask, q.h32, q.h16, cm, 0, 1));
     const sprc_rowmap row0 = {1, Lt, 0};                                     // last_hidden_state[:, 0, :]  (rerank.py:388-390)
     RUN(head(m, st, cm, B, q.h16, m->text_proj, q.proj, row0));
     return sprc_l2norm_rows(q.proj, m->embed_dim, feat, feat16, m->embed_dim, B, m->embed_dim, dt, st);
@@ -689,7 +724,7 @@ extern "C" int sprc_qformer_itm(const sprc_qformer_model* m, const float* itm_w,
     RUN(sprc_qformer_embed(&e, st));
     // one Q-Former pass in call shape (ii) over cat(reference, candidate) tokens (:430-437)
     const KvSrc kvs{kv_a, tokens_a, index_a, kv_b, tokens_b, index_b, (int64_t)m->n_cross * 2 * Hd};
-    RUN(qf_stack(m, st, q, P, S, &kvs, q.mask, q.h32, q.h16, cm));
+    RUN(qf_stack(m, st, q, P, S, &kvs, q.mask, q.h32, q.h16, cm, 0, Lq));      // read: the query rows (itm_head)
     // itm_head on the query rows, mean over them, softmax, P(match)  (:439-445)
     return sprc_itm_head(q.h32, (int64_t)S * Hd, Lq, Hd, itm_w, itm_b, P, prob, st);
 }
