@@ -421,6 +421,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             OutT* const cbase = reinterpret_cast<OutT*>(p.C) + (int64_t)row0m * p.ldc;
             const float* const rbase = p.resid + (int64_t)row0m * p.ldr;
             const uint32_t ldc32 = (uint32_t)p.ldc, ldr32 = (uint32_t)p.ldr;
+            // The bias / scale vectors are retired HERE, by a wait on the straight-line path.  Left to hipcc, the wait for these (predicated) loads lands
+            // inside the first row's bounds-checked block; the path around that block still carries them as pending, so the wait is repeated in
+            // EVERY row's block -- as `s_waitcnt vmcnt(1)` / `vmcnt(0)`, which in hardware waits for the PREVIOUS row's global store to complete:
+            // 16 serial store round trips per wave and tile (the 11 k cycles of the 16-bit epilogue; seen in the .s of every 16-bit-output kernel).
+            __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0); lgkmcnt / expcnt untouched
             auto body = [&](auto res_) {
                 constexpr bool RES = decltype(res_)::value;
                 f32x4 rv[2][ITERS][NV];
