@@ -16,6 +16,9 @@
 #include <type_traits>
 
 #include "common.hpp"
+#ifndef SPRC_ATTN_NT
+#define SPRC_ATTN_NT 0
+#endif
 
 namespace sprc {
 
@@ -544,7 +547,11 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
         for (int idx = lane; idx < 32 * cpr; idx += 64) {
             const int row = idx / cpr, c = idx - row * cpr;
             if (qt * 32 + row < p.Tq)
+#if SPRC_ATTN_NT & 1
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(so + row * ORS + c * 16), reinterpret_cast<u32x4*>(obase + (int64_t)row * p.ldo * 2 + c * 16));
+#else
                 *reinterpret_cast<u32x4*>(obase + (int64_t)row * p.ldo * 2 + c * 16) = *reinterpret_cast<const u32x4*>(so + row * ORS + c * 16);
+#endif
         }
     }
 }
@@ -568,7 +575,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_stream_kernel(AttnParams p, i
 template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void attn_dma16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t voffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_dst, 16, voffset, 0, 0, (SPRC_ATTN_NT & 2) ? 2 : 0);
 }
 __device__ __forceinline__ u32x2 attn_tr_read(const char* lds_src) {
     typedef short v4s __attribute__((ext_vector_type(4)));
@@ -676,7 +683,11 @@ __global__ __launch_bounds__(64 * NW, NBUF == 2 ? 4 : 3) void attn_dma_kernel(At
     for (int ks = 0; ks < KS; ++ks) {
         const int d0 = ks * 16 + half * 8;
         u32x4 val = {0u, 0u, 0u, 0u};
+#if SPRC_ATTN_NT & 4
+        if (d0 < dh) val = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qptr + d0 * 2));
+#else
         if (d0 < dh) val = *reinterpret_cast<const u32x4*>(qptr + d0 * 2);
+#endif
         qf[ks] = val;
     }
 
@@ -860,7 +871,11 @@ __global__ __launch_bounds__(64 * NW, NBUF == 2 ? 4 : 3) void attn_dma_kernel(At
         for (int idx = lane; idx < 32 * cpr; idx += 64) {
             const int row = idx / cpr, c = idx - row * cpr;
             if (qt * 32 + row < p.Tq)
+#if SPRC_ATTN_NT & 1
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x4*>(so + row * ORS + c * 16), reinterpret_cast<u32x4*>(obase + (int64_t)row * p.ldo * 2 + c * 16));
+#else
                 *reinterpret_cast<u32x4*>(obase + (int64_t)row * p.ldo * 2 + c * 16) = *reinterpret_cast<const u32x4*>(so + row * ORS + c * 16);
+#endif
         }
     };
     if (ONES) store_rows(11);                 // head_dim 88 (compile-time divisor: the run-time division cost ~25 VALU per piece)

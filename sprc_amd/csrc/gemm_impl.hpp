@@ -95,12 +95,25 @@ __device__ __forceinline__ uint32_t pack_fp8x2(float a, float b, uint32_t old, b
     b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
     return hi ? (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, true) : (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, (int)old, false);
 }
+// Cache policy of the epilogue's global accesses (bit mask; -DSPRC_EPI_NT=0 is the A/B build without any hint).  1: the 16-byte stores of outputs
+// narrower than fp32 are NON-TEMPORAL (`global_store_dwordx4 ... nt`): at the end of a round 256 workgroups write 33 MB of qkv / fc1 output at
+// once -- more than the L2s hold -- and with the default write-allocate policy that burst evicts the A / W panels every CU re-reads in the next
+// round.  Same box, round-robin (profiles/r06_nt_ab.txt): 87.61 -> 86.76 ms per bench step, GEMM class 78.2 -> 77.2 ms.  2: fp32 stores as well
+// (86.72: neutral -- the LayerNorm reads x right behind them), 4: non-temporal residual loads (neutral).  NT on the staging LOADS of either operand costs
+// 3-4 ms (SPRC_LD_NT), NT attention loads 1.5 ms, NT stores of the attention output or of the LayerNorm's 16-bit copy 0.2-0.3 ms: those are re-read.
+#ifndef SPRC_EPI_NT
+#define SPRC_EPI_NT 1
+#endif
 // 4 consecutive outputs of one row: 16 B (fp32) or 8 B (bf16 / fp16)
 // n_split / col: logical row width N and this quad's first column (SPRC_F16X3 outputs only: the e4m3 segments sit behind the N fp16 values)
 template <typename OutT>
 __device__ __forceinline__ void store_out4(OutT* dst, const f32x4& v, int n_split = 0, int col = 0) {
     if constexpr (std::is_same<OutT, float>::value) {
+#if SPRC_EPI_NT & 2
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#else
         *reinterpret_cast<f32x4*>(dst) = v;
+#endif
     } else if constexpr (std::is_same<OutT, f16x3_t>::value) {
         store_split4(reinterpret_cast<char*>(dst) - 2 * col, n_split, col, v[0], v[1], v[2], v[3]);
     } else if constexpr (std::is_same<OutT, f16_t>::value) {
@@ -120,13 +133,26 @@ __device__ __forceinline__ void store_out8(OutT* dst, const f32x4& a, const f32x
     if constexpr (std::is_same<OutT, f16x3_t>::value) {
         store_split8(reinterpret_cast<char*>(dst) - 2 * col, n_split, col, a, b);
     } else if constexpr (std::is_same<OutT, f16_t>::value) {
+#if SPRC_EPI_NT & 1
+        __builtin_nontemporal_store(u32x4{pack_f16x2(a[0], a[1]), pack_f16x2(a[2], a[3]), pack_f16x2(b[0], b[1]), pack_f16x2(b[2], b[3])}, reinterpret_cast<u32x4*>(dst));
+#else
         *reinterpret_cast<u32x4*>(dst) = u32x4{pack_f16x2(a[0], a[1]), pack_f16x2(a[2], a[3]), pack_f16x2(b[0], b[1]), pack_f16x2(b[2], b[3])};
+#endif
     } else if constexpr (std::is_same<OutT, fp8_t>::value) {
+#if SPRC_EPI_NT & 1
+        __builtin_nontemporal_store(u32x2{pack_fp8x2(a[2], a[3], pack_fp8x2(a[0], a[1], 0u, false), true),
+                                          pack_fp8x2(b[2], b[3], pack_fp8x2(b[0], b[1], 0u, false), true)}, reinterpret_cast<u32x2*>(dst));
+#else
         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_fp8x2(a[2], a[3], pack_fp8x2(a[0], a[1], 0u, false), true),
                                                pack_fp8x2(b[2], b[3], pack_fp8x2(b[0], b[1], 0u, false), true)};
+#endif
     } else {
         static_assert(std::is_same<OutT, bf16_t>::value, "store_out8: outputs narrower than fp32");
+#if SPRC_EPI_NT & 1
+        __builtin_nontemporal_store(u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])}, reinterpret_cast<u32x4*>(dst));
+#else
         *reinterpret_cast<u32x4*>(dst) = u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+#endif
     }
 }
 
@@ -152,8 +178,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xffffffff, 0x00020000);
 }
+#ifndef SPRC_LD_NT
+#define SPRC_LD_NT 0
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rs, char* lds_dst, uint32_t voffset, int soffset) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds_dst, 16, voffset, soffset, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)lds_dst, 16, voffset, soffset, 0, AUX);     // AUX 2 = nt (gfx940+ cache policy bits: 1 sc0, 2 nt, 16 sc1)
 }
 
 template <int I, int N, typename F>
@@ -434,7 +464,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
                     for (int it = 0; it < ITERS; ++it) {
                         const uint32_t ro = __umul24((uint32_t)(mrow(min(block_row(mi, it), p.M - 1)) - row0m), ldr32) + (uint32_t)colc;
 #pragma unroll
+#if SPRC_EPI_NT & 4
+                        for (int j = 0; j < NV; ++j) dst[it][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rbase + ro + 4 * j));
+#else
                         for (int j = 0; j < NV; ++j) dst[it][j] = *reinterpret_cast<const f32x4*>(rbase + ro + 4 * j);
+#endif
                     }
                 };
                 if constexpr (RES) {
@@ -893,7 +927,8 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     // load j (of 2) of piece q (G0: B0 B1 | A2 A3, G1: B2 B3 | A0 A1) of K-tile `tile` into the stage of parity par_bytes / 32 KB
     auto load_piece = [&](auto q_, auto j_, uint32_t par_bytes, int tile) {
         constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
-        buffer_load_lds16(q >= 2 ? rs_a : rs_w, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
+        if constexpr (q >= 2) buffer_load_lds16<(SPRC_LD_NT & 1) ? 2 : 0>(rs_a, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
+        else buffer_load_lds16<(SPRC_LD_NT & 2) ? 2 : 0>(rs_w, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
     };
     auto piece = [&](auto q_, uint32_t par_bytes, int tile) { load_piece(q_, I0{}, par_bytes, tile); load_piece(q_, I1{}, par_bytes, tile); };
     // fragments of k-steps 2h, 2h+1 of the K-tile in the stage of parity PAR: compile-time parity = pure immediates

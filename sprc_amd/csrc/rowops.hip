@@ -7,6 +7,12 @@
 
 namespace sprc {
 
+// Cache policy of the row kernels (bit mask, -DSPRC_LN_NT=0: no hints).  2: the fp32 row is LOADED non-temporally -- the residual stream is read once
+// here and next by a GEMM epilogue a whole product later (86.76 -> 86.54 ms per bench step on top of the GEMM's non-temporal stores); 1: non-temporal
+// stores of the 16-bit copy -- the next GEMM's A operand -- cost 0.15 ms and stay off (profiles/r06_nt_ab.txt).
+#ifndef SPRC_LN_NT
+#define SPRC_LN_NT 2
+#endif
 constexpr int MAXC = 8;          // float4 chunks per lane -> D <= 64*4*8 = 2048
 constexpr int ROWS_PER_BLOCK = 4;
 
@@ -18,7 +24,12 @@ __device__ __forceinline__ void load_row(RowRegs& r, const float* x, int nch, in
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int i = lane + c * 64;
+#if SPRC_LN_NT & 2
+        if (i < nch) { const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x) + i); r.v[c] = make_float4(t[0], t[1], t[2], t[3]); }
+        else r.v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
         r.v[c] = (i < nch) ? reinterpret_cast<const float4*>(x)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     }
 }
 
@@ -66,7 +77,11 @@ __device__ __forceinline__ void store_row(const RowRegs& r, float* y32, void* y1
                     uint2 pk;
                     pk.x = pack16x2<KIND == 2>(r.v[c].x, r.v[c].y);
                     pk.y = pack16x2<KIND == 2>(r.v[c].z, r.v[c].w);
+#if SPRC_LN_NT & 1
+                    __builtin_nontemporal_store(u32x2{pk.x, pk.y}, reinterpret_cast<u32x2*>(y16) + i);
+#else
                     reinterpret_cast<uint2*>(y16)[i] = pk;
+#endif
                 } else {
                     reinterpret_cast<float4*>(y16)[i] = r.v[c];
                 }
