@@ -1252,8 +1252,12 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     optin_lds(kern, LDS, attr_set);
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
-    static const int order = env_int("SPRC_GEMM_ORDER", 4);     // W-resident groups of 4 n-tiles: +8 % on N = 9216, neutral else
-    p.order = order;
+    // Tile order: 8-m-tile groups walking all their n-tiles (mode 0) -- since the 16-bit outputs are stored non-temporally this beats the W-resident
+    // groups of 4 n-tiles (mode 4) that round 2 chose: same box, round-robin, 87.31 -> 86.62 ms per pipelined bench step (and 91.8 -> 91.1 on the slowest
+    // box seen); in a traced single-stream step proj + fc2 go 327 -> 317 us per launch, fc1 524 -> 532, qkv stays (profiles/r06_order_ab.txt).  Mode 4 keeps
+    // the one shape it was found on: N = 9216 (36 n-tiles, the cross-attention K|V projection: +8 %).  SPRC_GEMM_ORDER forces one mode everywhere (A/B).
+    static const int order = env_int("SPRC_GEMM_ORDER", -1);
+    p.order = order >= 0 ? order : (p.tiles_n >= 32 ? 4 : 0);
     p.nwg0 = p.tiles_m * p.tiles_n;
     // one workgroup per CU that walks its tiles (SPRC_GEMM_PERSIST=0: one workgroup per tile, the A/B switch).  Same box, pipelined bench step:
     // 90.13 / 90.24 ms (the kernel without the tile loop) -> 90.48 / 90.38 (this kernel, one workgroup per tile) -> 89.23 / 89.40 (persistent);
