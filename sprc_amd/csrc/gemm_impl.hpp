@@ -927,8 +927,9 @@ __global__ __launch_bounds__(512) void gemm_anti_kernel(GemmParams p) {
     // load j (of 2) of piece q (G0: B0 B1 | A2 A3, G1: B2 B3 | A0 A1) of K-tile `tile` into the stage of parity par_bytes / 32 KB
     auto load_piece = [&](auto q_, auto j_, uint32_t par_bytes, int tile) {
         constexpr int q = decltype(q_)::value, j = decltype(j_)::value;
-        if constexpr (q >= 2) buffer_load_lds16<(SPRC_LD_NT & 1) ? 2 : 0>(rs_a, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
-        else buffer_load_lds16<(SPRC_LD_NT & 2) ? 2 : 0>(rs_w, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
+        // SPRC_LD_NT (A/B builds only): bit 0 / 1 = nt on the A / W loads (measured: +3-4 ms per step), bit 2 / 3 = sc0 on them
+        if constexpr (q >= 2) buffer_load_lds16<((SPRC_LD_NT & 1) ? 2 : 0) | ((SPRC_LD_NT & 4) ? 1 : 0)>(rs_a, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
+        else buffer_load_lds16<((SPRC_LD_NT & 2) ? 2 : 0) | ((SPRC_LD_NT & 8) ? 1 : 0)>(rs_w, smem + (base_q[q] + par_bytes + j * 4096), pc_off[q][j], tile * KTB);
     };
     auto piece = [&](auto q_, uint32_t par_bytes, int tile) { load_piece(q_, I0{}, par_bytes, tile); load_piece(q_, I1{}, par_bytes, tile); };
     // fragments of k-steps 2h, 2h+1 of the K-tile in the stage of parity PAR: compile-time parity = pure immediates
