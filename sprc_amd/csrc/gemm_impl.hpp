@@ -350,8 +350,8 @@ __device__ __forceinline__ void pipe_ktile_bf16(uint32_t a_base, uint32_t b_base
 __device__ __forceinline__ void tile_origin(int vb, int nwg, int tiles_m, int tiles_n, int BM, int BN, int mode, int& m0, int& n0) {
     const int xcd = vb & 7, q = nwg >> 3, r = nwg & 7;
     const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
-    if (mode == 0) {
-        constexpr int GROUP_M = 8;
+    if ((mode & 255) == 0) {
+        const int GROUP_M = (mode >> 8) ? (mode >> 8) : 4;     // SPRC_GEMM_ORDER = 0 | GROUP_M << 8 forces another group height (A/B)
         const int in_group = GROUP_M * tiles_n;
         const int first_m = (pid / in_group) * GROUP_M;
         const int gsz = min(tiles_m - first_m, GROUP_M);
@@ -1222,7 +1222,7 @@ static int launch_cfg(GemmParams p, hipStream_t st) {
     optin_lds(kern, LDS, attr_set);
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    static const int order = env_int("SPRC_GEMM_ORDER", 0);     // 8-m grouped order is better for the K-heavy 128x128 GEMMs
+    static const int order = env_int("SPRC_GEMM_ORDER", 8 << 8);     // 8-m grouped order (mode 0, GROUP_M 8) is better for the K-heavy 128x128 GEMMs
     p.order = order;
     const int nwg = p.tiles_m * p.tiles_n;
     p.nwg0 = nwg;
@@ -1253,7 +1253,8 @@ static int launch_anti(GemmParams p, hipStream_t st) {
     optin_lds(kern, LDS, attr_set);
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
-    // Tile order: 8-m-tile groups walking all their n-tiles (mode 0) -- since the 16-bit outputs are stored non-temporally this beats the W-resident
+    // Tile order: groups of GROUP_M = 4 m-tiles walking all their n-tiles (mode 0; 4 beats 8 by another 0.65-0.9 % of the step, 2 ties, 1 / 6 / 16 / 32 lose:
+    // profiles/r06_order_ab.txt) -- since the 16-bit outputs are stored non-temporally this beats the W-resident
     // groups of 4 n-tiles (mode 4) that round 2 chose: same box, round-robin, 87.31 -> 86.62 ms per pipelined bench step (and 91.8 -> 91.1 on the slowest
     // box seen); in a traced single-stream step proj + fc2 go 327 -> 317 us per launch, fc1 524 -> 532, qkv stays (profiles/r06_order_ab.txt).  Mode 4 keeps
     // the one shape it was found on: N = 9216 (36 n-tiles, the cross-attention K|V projection: +8 %).  SPRC_GEMM_ORDER forces one mode everywhere (A/B).
