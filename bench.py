@@ -26,6 +26,24 @@ import os
 import sys
 import time
 
+# HIP's runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (ROCm default 4; streams beyond that share them, which ones depends on the
+# order the runtime saw the streams).  The pipelined step has three streams in flight (the ViT, the gallery-side and the query-side Q-Former
+# passes): with TWO hardware queues it is 0.8-1.0 % faster than with 3, 4 or 8 on every box measured, and ONE queue reproduces the slow mode some
+# boxes fell into with the default (step / GEMM-class time 1.16 instead of 1.11: profiles/r06_hwq_sweep.txt).  Set before the HIP runtime starts,
+# for the single-process run only (ranks of an N > 1 job keep the runtime's default: RCCL's streams have never been measured under it); a value in
+# the caller's environment wins.
+def _gpus_arg(argv) -> int:
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv) and argv[i + 1].isdigit():
+            return int(argv[i + 1])
+        if a.startswith("--gpus=") and a[7:].isdigit():
+            return int(a[7:])
+    return 1
+
+
+if int(os.environ.get("WORLD_SIZE", "1")) == 1 and _gpus_arg(sys.argv[1:]) == 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -615,7 +633,7 @@ def main():
                                    f"{'ViT-g' if a.backbone == 'pretrain' else 'ViT-L'} {a.dtype}, batch {BATCH}; step = encode {BATCH} images + "
                                    f"fuse {Q_PER_STEP} queries + rank vs {GALLERY} (top-{TOPK})",
                        "backbone": a.backbone, "batch": BATCH, "queries_per_step": Q_PER_STEP, "gallery": GALLERY,
-                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_group": a.qf_group, "qformer_streams": a.qf_streams, "pipeline": int(bool(a.pipeline)),
+                       "topk": TOPK, "rank_dtype": "fp32", "sharding": f"gallery-sharded x{world}", "vit_streams": a.vit_streams, "qformer_group": a.qf_group, "qformer_streams": a.qf_streams, "pipeline": int(bool(a.pipeline)), "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                        "precision": precision, "rccl_ranks": (torch.distributed.get_world_size() if use_dist and backend == "nccl" else None),
                        "per_rank_ms_per_step": per_rank_ms,
                        "backend": ("rccl" if backend == "nccl" else f"gloo ({world} ranks sharing {ndev} GPU: plumbing check, not a scaling number)") if use_dist else None},
